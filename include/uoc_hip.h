@@ -1,0 +1,77 @@
+/*
+ * uoc_hip.h — C ABI of libuoc_hip.so, the MI355X (gfx950) native library behind the
+ * reference's Python call surface for the inference hot path
+ * (the reference has no FFI layer — these entry points are what a ctypes
+ * binding for that path binds).
+ *
+ * Conventions
+ *   - every pointer named d_* is a DEVICE pointer into caller-owned memory (a torch tensor);
+ *     the library allocates nothing across the boundary except the opaque net handle.
+ *   - every function returns 0 on success or a negative errno-style code; it never throws.
+ *     uoc_last_error() returns a thread-local message for the last failure.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing
+ *     synchronises unless documented.
+ *   - embeddings ("X") are PIXEL-MAJOR: [batch][n][64] fp32, one 256-byte row per pixel.
+ *     This is the layout the fused backbone head writes and the clustering kernels read.
+ */
+#ifndef UOC_HIP_H
+#define UOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UOC_OK 0
+#define UOC_EINVAL (-22)
+#define UOC_ENOMEM (-12)
+#define UOC_EHIP (-5)
+#define UOC_ENOENT (-2)
+
+#define UOC_EMBED_DIM 64   /* channel count C the kernels are specialised for */
+#define UOC_MAX_SEEDS 128  /* num_seeds upper bound (reference default 100)   */
+
+int uoc_version(void);
+const char *uoc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Mean-shift clustering  — replaces lib/utils/mean_shift.py:128-229 (cosine metric)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Scratch bytes the clustering entry points need for (batch, n, m). */
+size_t uoc_ms_workspace_bytes(int batch, int n, int m);
+
+/* Farthest-point seed selection — select_smart_seeds, mean_shift.py:128-189.
+ * d_first_index [batch] int32: the index the reference draws with np.random.randint (:155).
+ * d_seeds [batch][m][64], d_indices [batch][m] int32. */
+int uoc_ms_select_seeds(const float *d_X, int batch, int n, int m, const int32_t *d_first_index,
+                        float *d_seeds, int32_t *d_indices, void *d_ws, size_t ws_bytes, void *stream);
+
+/* iters x { W = exp(kappa Z X^T); Z = normalize(W X) } — seed_hill_climbing_ball,
+ * mean_shift.py:79-109 with ball_kernel :26.  d_Z [batch][m][64] is updated in place. */
+int uoc_ms_hill_climb(const float *d_X, int batch, int n, float *d_Z, int m, float kappa, int iters,
+                      void *d_ws, size_t ws_bytes, void *stream);
+
+/* Sequential epsilon-ball labelling of the seeds — connected_components, mean_shift.py:41-76.
+ * d_seed_labels [batch][m] int32; d_num_unique [batch] int32 = len(unique(seed labels)). */
+int uoc_ms_seed_components(const float *d_Z, int batch, int m, float epsilon, int32_t *d_seed_labels,
+                           int32_t *d_num_unique, void *stream);
+
+/* Nearest-seed assignment + "largest cluster becomes label 0" — mean_shift.py:211-227.
+ * d_labels [batch][n] int32; d_closest (nullable) [batch][n] int32 = argmin seed. */
+int uoc_ms_assign(const float *d_X, int batch, int n, const float *d_Z, const int32_t *d_seed_labels,
+                  const int32_t *d_num_unique, int m, int32_t *d_labels, int32_t *d_closest,
+                  void *d_ws, size_t ws_bytes, void *stream);
+
+/* The four stages above back to back — mean_shift_smart_init, mean_shift.py:192-229.
+ * d_Z_out (nullable) receives the converged seeds, d_seed_labels_out (nullable) their labels. */
+int uoc_ms_cluster(const float *d_X, int batch, int n, int m, float kappa, int iters, float epsilon,
+                   const int32_t *d_first_index, int32_t *d_labels, int32_t *d_indices,
+                   float *d_Z_out, int32_t *d_seed_labels_out, void *d_ws, size_t ws_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UOC_HIP_H */

@@ -1,0 +1,54 @@
+"""The C-ABI library builds, loads, and exports every symbol include/uoc_hip.h declares.
+No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from unseenobjectclustering_amd import _native
+from unseenobjectclustering_amd.build import LIB_PATH, build_native
+
+HEADER = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "uoc_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(uoc_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_loads():
+    path = build_native()
+    assert os.path.exists(path)
+    lib = _native.lib()
+    assert lib.uoc_version() >= 100
+
+
+def test_every_declared_symbol_is_exported():
+    build_native()
+    lib = ctypes.CDLL(LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 8
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/uoc_hip.h but not exported by libuoc_hip.so"
+    assert set(_native.EXPORTED_SYMBOLS) == set(syms)
+
+
+def test_argument_validation_without_gpu():
+    """Validation errors are reported through the error channel before any HIP call."""
+    lib = _native.lib()
+    assert lib.uoc_ms_workspace_bytes(1, 307200, 100) > 307200 * 4
+    rc = lib.uoc_ms_cluster(None, 1, 100, 100, 20.0, 10, 0.04, None, None, None, None, None, None, 0, None)
+    assert rc == -22
+    assert b"null" in lib.uoc_last_error().lower()
+    rc = lib.uoc_ms_seed_components(None, 1, 1000, 0.04, None, None, None)
+    assert rc == -22
+
+
+def test_product_path_refuses_cpu_tensors():
+    import torch
+    from unseenobjectclustering_amd.utils.mean_shift import mean_shift_smart_init
+    X = torch.nn.functional.normalize(torch.randn(128, 64), dim=1)
+    with pytest.raises(_native.NativeError):
+        mean_shift_smart_init(X, 20.0)

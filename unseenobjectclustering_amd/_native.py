@@ -1,0 +1,69 @@
+"""ctypes binding of libuoc_hip.so (include/uoc_hip.h).  No CPU fallback: if the library is
+missing or a call fails, this raises — the product path never routes around the HIP kernels."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p, POINTER
+
+from .build import LIB_PATH
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def _declare(lib):
+    P = c_void_p
+    lib.uoc_version.restype = c_int
+    lib.uoc_last_error.restype = c_char_p
+    lib.uoc_ms_workspace_bytes.restype = c_size_t
+    lib.uoc_ms_workspace_bytes.argtypes = [c_int, c_int, c_int]
+    lib.uoc_ms_select_seeds.argtypes = [P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]
+    lib.uoc_ms_hill_climb.argtypes = [P, c_int, c_int, P, c_int, c_float, c_int, P, c_size_t, P]
+    lib.uoc_ms_seed_components.argtypes = [P, c_int, c_int, c_float, P, P, P]
+    lib.uoc_ms_assign.argtypes = [P, c_int, c_int, P, P, P, c_int, P, P, P, c_size_t, P]
+    lib.uoc_ms_cluster.argtypes = [P, c_int, c_int, c_int, c_float, c_int, c_float, P, P, P, P, P, P, c_size_t, P]
+    for name in ("uoc_ms_select_seeds", "uoc_ms_hill_climb", "uoc_ms_seed_components", "uoc_ms_assign",
+                 "uoc_ms_cluster"):
+        getattr(lib, name).restype = c_int
+
+
+# every symbol include/uoc_hip.h declares (tests check the .so exports them all)
+EXPORTED_SYMBOLS = (
+    "uoc_version", "uoc_last_error", "uoc_ms_workspace_bytes", "uoc_ms_select_seeds", "uoc_ms_hill_climb",
+    "uoc_ms_seed_components", "uoc_ms_assign", "uoc_ms_cluster",
+)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build it with `python -m unseenobjectclustering_amd.build` "
+                "(or __graft_entry__.build()).  There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        _declare(l)
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().uoc_last_error().decode("utf-8", "replace")
+        raise NativeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor as c_void_p; None -> NULL."""
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,59 @@
+"""Builds libuoc_hip.so (the C-ABI library, include/uoc_hip.h) in-tree with hipcc for gfx950.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting .so
+travels to the GPU box with the repo snapshot (git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import glob
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libuoc_hip.so")
+ARCH = "gfx950"
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
+        glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h"))
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """Compile every csrc/*.hip into libuoc_hip.so.  Returns the library path."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libuoc_hip.so")
+    objs = []
+    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    for src in sources():
+        obj = os.path.join(CSRC, "build", os.path.basename(src)[:-4] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
+                os.path.getmtime(src), *[os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h"))],
+                *[os.path.getmtime(h) for h in glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h"))]):
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+        objs.append(obj)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_native(force=True, verbose=True))

@@ -1,0 +1,57 @@
+// Shared helpers for libuoc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/uoc_hip.h"
+
+namespace uoc {
+
+void set_error(const char *fmt, ...);
+
+#define UOC_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ::uoc::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return UOC_EHIP;                                                                   \
+    }                                                                                    \
+  } while (0)
+
+#define UOC_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      ::uoc::set_error(__VA_ARGS__);  \
+      return UOC_EINVAL;              \
+    }                                 \
+  } while (0)
+
+#define UOC_LAUNCH_CHECK() UOC_HIP_CHECK(hipGetLastError())
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- wave64 cross-lane helpers (DPP; one VALU op each, no LDS) -------------------------
+// Row = 16 lanes.  quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,
+// row_mirror = 0x140.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+// Sum over each 16-lane row; every lane of the row ends with the bitwise-identical total.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  return v;
+}
+
+}  // namespace uoc

@@ -1,0 +1,699 @@
+// Seeded von-Mises-Fisher mean-shift clustering on gfx950 — hand-written HIP.
+//
+// Replaces /root/reference/lib/utils/mean_shift.py (cosine metric):
+//   select_smart_seeds       :128-189  -> fps_step_kernel        (HBM/L2-bound streaming + grid argmax)
+//   seed_hill_climbing_ball  :79-109   -> hc_iter_kernel         (fp32 MFMA, W never materialised)
+//                                         + hc_finalize_kernel   (partial reduce + L2 normalise)
+//   connected_components     :41-76    -> seed_cc_kernel         (one wavefront, ballots)
+//   mean_shift_smart_init    :211-227  -> assign_kernel          (fp32 MFMA + row argmin + histogram)
+//                                         + relabel_swap_kernel  (largest cluster <-> label 0)
+//
+// Data layout: X is pixel-major [batch][n][64] fp32 (256 B per pixel), seeds Z [batch][m][64].
+// All reductions have a fixed order, so results are run-to-run deterministic.
+#include "common.h"
+
+#include <limits.h>
+#include <math.h>
+
+namespace uoc {
+
+constexpr int C = UOC_EMBED_DIM;  // 64 channels
+constexpr int FPS_THREADS = 256;
+constexpr int FPS_MAX_BLOCKS = 1024;
+constexpr int HC_THREADS = 256;
+constexpr int HC_MAX_BLOCKS = 1024;
+constexpr int ZP = 68;  // LDS row pitch (floats) of the seed tile: 4-dword skew per row
+constexpr int NLAB = UOC_MAX_SEEDS;
+
+struct ArgMax {
+  float val;
+  int idx;
+};
+
+__device__ __forceinline__ bool better(const ArgMax &a, const ArgMax &b) {
+  // torch.argmax semantics: larger value wins, ties -> lower index.
+  return a.val > b.val || (a.val == b.val && a.idx < b.idx);
+}
+
+__device__ __forceinline__ ArgMax wave_argmax(ArgMax v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    ArgMax o;
+    o.val = __shfl_xor(v.val, off);
+    o.idx = __shfl_xor(v.idx, off);
+    if (better(o, v)) v = o;
+  }
+  return v;
+}
+
+// -------------------------------------------------------------------------------------------
+// Farthest-point seed selection, one launch per step.
+//   step s: (a) every block reduces the previous step's per-block argmax partials -> index of
+//   seed s; (b) block 0 records seed s; (c) all blocks stream X once: d = 0.5(1 - x.seed),
+//   dmin = min(dmin, d), per-block argmax(dmin) -> partials for step s+1.
+// 16 lanes share one pixel row (float4 each => a wave reads 1 KiB contiguous per load).
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
+    const float *__restrict__ X, int n, int m, int step, const int *__restrict__ first_index,
+    float *__restrict__ dmin, float *__restrict__ seeds, int *__restrict__ indices,
+    const ArgMax *__restrict__ part_in, ArgMax *__restrict__ part_out) {
+  const int b = blockIdx.y;
+  const int nblk = gridDim.x;
+  X += (size_t)b * n * C;
+  dmin += (size_t)b * n;
+  seeds += (size_t)b * m * C;
+  indices += (size_t)b * m;
+  part_in += (size_t)b * FPS_MAX_BLOCKS;
+  part_out += (size_t)b * FPS_MAX_BLOCKS;
+
+  __shared__ ArgMax red[FPS_THREADS / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+  int cur;
+  if (step == 0) {
+    cur = first_index[b];
+  } else {
+    ArgMax best = {-INFINITY, INT_MAX};
+    for (int i = tid; i < nblk; i += FPS_THREADS) {
+      ArgMax a = part_in[i];
+      if (better(a, best)) best = a;
+    }
+    best = wave_argmax(best);
+    if (lane == 0) red[wave] = best;
+    __syncthreads();
+    best = red[0];
+#pragma unroll
+    for (int w = 1; w < FPS_THREADS / 64; ++w)
+      if (better(red[w], best)) best = red[w];
+    cur = best.idx;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0) {
+    if (tid == 0) indices[step] = cur;
+    if (tid < C) seeds[(size_t)step * C + tid] = X[(size_t)cur * C + tid];
+  }
+  if (step == m - 1) return;  // the distances to the last seed are never consumed (:174 uses [:, :i])
+
+  const int t = lane & 15, g = lane >> 4;
+  const float4 sv = *reinterpret_cast<const float4 *>(X + (size_t)cur * C + 4 * t);
+  ArgMax best = {-INFINITY, INT_MAX};
+  const int nchunk = (n + 63) >> 6;
+  for (int chunk = blockIdx.x * (FPS_THREADS / 64) + wave; chunk < nchunk; chunk += nblk * (FPS_THREADS / 64)) {
+    const int base = chunk << 6;
+    float4 x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = base + 4 * i + g;
+      x[i] = (p < n) ? *reinterpret_cast<const float4 *>(X + (size_t)p * C + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float s = x[i].x * sv.x;
+      s = fmaf(x[i].y, sv.y, s);
+      s = fmaf(x[i].z, sv.z, s);
+      s = fmaf(x[i].w, sv.w, s);
+      s = row16_sum(s);
+      if (t == i) mine = s;
+    }
+    const int p = base + 4 * t + g;
+    if (p < n) {
+      float d = 0.5f * (1.0f - mine);
+      if (step > 0) d = fminf(d, dmin[p]);
+      dmin[p] = d;
+      if (d > best.val) {  // p ascends per lane: strict '>' keeps the lowest index
+        best.val = d;
+        best.idx = p;
+      }
+    }
+  }
+  best = wave_argmax(best);
+  if (lane == 0) red[wave] = best;
+  __syncthreads();
+  if (tid == 0) {
+    best = red[0];
+#pragma unroll
+    for (int w = 1; w < FPS_THREADS / 64; ++w)
+      if (better(red[w], best)) best = red[w];
+    part_out[blockIdx.x] = best;
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// One hill-climbing iteration.  Each wave owns 16-pixel tiles and all ST seed tiles:
+//   S^T[pixel][seed] = X Z^T       16 x v_mfma_f32_16x16x4_f32 per (16 px x 16 seeds)
+//   W = exp(kappa S)               in registers: the D fragment of step 1 IS the A fragment of step 3
+//   acc[seed][chan] += W^T X       16 x v_mfma_f32_16x16x4_f32
+// K-index (channel) and N-index (channel) permutations are chosen so every global load is a
+// float4: xa[v] = X[p=t][16v+4q..], xb[r] = X[p=4q+r][4t..].  W (122.9 MB in the reference) never
+// exists in memory.  Wave partials are reduced through LDS; block partials go to HBM and are
+// reduced (fixed order) + L2-normalised by hc_finalize_kernel.
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int ST>
+__global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__restrict__ X, int n,
+                                                             const float *__restrict__ Z, int m, float kappa,
+                                                             float *__restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Zs = smem;  // [ST*16][ZP]; later reused as the cross-wave reduction buffer
+  const int b = blockIdx.y;
+  const int nblk = gridDim.x;
+  X += (size_t)b * n * C;
+  Z += (size_t)b * m * C;
+  partial += ((size_t)b * nblk + blockIdx.x) * (ST * 16) * C;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 15, q = lane >> 4;
+
+  for (int i = tid; i < ST * 16 * (C / 4); i += HC_THREADS) {
+    const int row = i / (C / 4), c4 = i % (C / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < m) v = *reinterpret_cast<const float4 *>(Z + (size_t)row * C + 4 * c4);
+    *reinterpret_cast<float4 *>(Zs + row * ZP + 4 * c4) = v;
+  }
+  __syncthreads();
+
+  f32x4 acc[ST][4];
+#pragma unroll
+  for (int s = 0; s < ST; ++s)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[s][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ntile = (n + 15) >> 4;
+  const int stride = nblk * (HC_THREADS / 64);
+  int tile = blockIdx.x * (HC_THREADS / 64) + wave;
+
+  float4 xa[4], xb[4];
+  auto load_tile = [&](int tl, float4(&a)[4], float4(&bb)[4]) {
+    const int pa = tl * 16 + t;
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      a[v] = (tl < ntile && pa < n) ? *reinterpret_cast<const float4 *>(X + (size_t)pa * C + 16 * v + 4 * q)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int pb = tl * 16 + 4 * q + r;
+      bb[r] = (tl < ntile && pb < n) ? *reinterpret_cast<const float4 *>(X + (size_t)pb * C + 4 * t)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  load_tile(tile, xa, xb);
+
+  for (; tile < ntile; tile += stride) {
+    float4 na[4], nb[4];
+    load_tile(tile + stride, na, nb);  // software prefetch of the wave's next tile
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+      f32x4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float4 zb = *reinterpret_cast<const float4 *>(Zs + (16 * s + t) * ZP + 16 * v + 4 * q);
+        S = mfma4(xa[v].x, zb.x, S);
+        S = mfma4(xa[v].y, zb.y, S);
+        S = mfma4(xa[v].z, zb.z, S);
+        S = mfma4(xa[v].w, zb.w, S);
+      }
+      float w[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = expf(kappa * S[r]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        acc[s][0] = mfma4(w[r], xb[r].x, acc[s][0]);
+        acc[s][1] = mfma4(w[r], xb[r].y, acc[s][1]);
+        acc[s][2] = mfma4(w[r], xb[r].z, acc[s][2]);
+        acc[s][3] = mfma4(w[r], xb[r].w, acc[s][3]);
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      xa[v] = na[v];
+      xb[v] = nb[v];
+    }
+  }
+
+  // ---- cross-wave reduction (fixed order: (w0 + w2) + (w1 + w3)) through LDS -------------
+  f32x4 *red = reinterpret_cast<f32x4 *>(smem);  // [2][ST*4][64] f32x4
+  __syncthreads();
+  if (wave >= 2) {
+#pragma unroll
+    for (int s = 0; s < ST; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) red[((wave - 2) * ST * 4 + s * 4 + ct) * 64 + lane] = acc[s][ct];
+  }
+  __syncthreads();
+  if (wave < 2) {
+#pragma unroll
+    for (int s = 0; s < ST; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[s][ct] += red[(wave * ST * 4 + s * 4 + ct) * 64 + lane];
+  }
+  __syncthreads();
+  if (wave == 1) {
+#pragma unroll
+    for (int s = 0; s < ST; ++s)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) red[(s * 4 + ct) * 64 + lane] = acc[s][ct];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) acc[s][ct] += red[(s * 4 + ct) * 64 + lane];
+      // lane (t,q) reg r holds newZ[seed 16s+4q+r][channel 4t+ct]
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float4 o = make_float4(acc[s][0][r], acc[s][1][r], acc[s][2][r], acc[s][3][r]);
+        *reinterpret_cast<float4 *>(partial + (size_t)(16 * s + 4 * q + r) * C + 4 * t) = o;
+      }
+    }
+  }
+}
+
+// Z[seed] = normalize(sum_blk partial[blk][seed])  (F.normalize, eps 1e-12; mean_shift.py:107)
+__global__ __launch_bounds__(256) void hc_finalize_kernel(const float *__restrict__ partial, int nblk, int rows,
+                                                          int m, float *__restrict__ Z) {
+  const int b = blockIdx.y, seed = blockIdx.x;
+  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float *src = partial + ((size_t)b * nblk * rows + seed) * C + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int blk = w;
+  for (; blk + 12 < nblk; blk += 16) {
+    s0 += src[(size_t)blk * rows * C];
+    s1 += src[(size_t)(blk + 4) * rows * C];
+    s2 += src[(size_t)(blk + 8) * rows * C];
+    s3 += src[(size_t)(blk + 12) * rows * C];
+  }
+  for (; blk < nblk; blk += 4) s0 += src[(size_t)blk * rows * C];
+  __shared__ float red[4][C];
+  red[w][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0) {
+    const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    float ss = v * v;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    Z[((size_t)b * m + seed) * C + c] = v / nrm;
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// Seed connected components: inherently sequential over seeds (mean_shift.py:53-74), m <= 128,
+// so ONE wavefront per batch item; lane l owns seeds l and l+64.  Quirks kept: the component
+// takes the MODE of already-present labels (ties -> smallest) and overwrites every member.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void seed_cc_kernel(const float *__restrict__ Z, int m, float eps,
+                                                     int *__restrict__ seed_labels, int *__restrict__ num_unique) {
+  __shared__ float Zs[NLAB * (C + 1)];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  Z += (size_t)b * m * C;
+  for (int i = lane; i < m * C; i += 64) Zs[(i / C) * (C + 1) + (i % C)] = Z[i];
+  __syncthreads();
+  const bool have0 = lane < m, have1 = lane + 64 < m;
+  int lab0 = -1, lab1 = -1, next = 0;
+  for (int i = 0; i < m; ++i) {
+    const int li = (i < 64) ? __shfl(lab0, i) : __shfl(lab1, i - 64);
+    if (li != -1) continue;
+    float dot0 = 0.f, dot1 = 0.f;
+    const float *zi = Zs + i * (C + 1);
+    const float *z0 = Zs + lane * (C + 1);
+    const float *z1 = Zs + (lane + 64) * (C + 1);
+    if (have0)
+      for (int c = 0; c < C; ++c) dot0 = fmaf(z0[c], zi[c], dot0);
+    if (have1)
+      for (int c = 0; c < C; ++c) dot1 = fmaf(z1[c], zi[c], dot1);
+    const bool in0 = have0 && (0.5f * (1.0f - dot0) <= eps);
+    const bool in1 = have1 && (0.5f * (1.0f - dot1) <= eps);
+    unsigned long long lm0 = __ballot(in0 && lab0 != -1), lm1 = __ballot(in1 && lab1 != -1);
+    const bool any_unl = (__ballot(in0 && lab0 == -1) | __ballot(in1 && lab1 == -1)) != 0ull;
+    // distinct values among members' labels (the value -1 counts as one, :66)
+    int best_cnt = 0, best_lab = INT_MAX, distinct = any_unl ? 1 : 0;
+    while (lm0 | lm1) {
+      const int L = lm0 ? __shfl(lab0, __ffsll((long long)lm0) - 1) : __shfl(lab1, __ffsll((long long)lm1) - 1);
+      const unsigned long long c0 = __ballot(in0 && lab0 == L), c1 = __ballot(in1 && lab1 == L);
+      const int cnt = __popcll(c0) + __popcll(c1);
+      if (cnt > best_cnt || (cnt == best_cnt && L < best_lab)) {
+        best_cnt = cnt;
+        best_lab = L;
+      }
+      ++distinct;
+      lm0 &= ~c0;
+      lm1 &= ~c1;
+    }
+    int lab;
+    if (distinct > 1) {
+      lab = best_lab;
+    } else {
+      lab = next++;
+    }
+    if (in0) lab0 = lab;
+    if (in1) lab1 = lab;
+  }
+  if (have0) seed_labels[(size_t)b * m + lane] = lab0;
+  if (have1) seed_labels[(size_t)b * m + lane + 64] = lab1;
+  // len(torch.unique(seed_labels)) (mean_shift.py:218)
+  unsigned long long r0 = __ballot(have0), r1 = __ballot(have1);
+  int uniq = 0;
+  while (r0 | r1) {
+    const int L = r0 ? __shfl(lab0, __ffsll((long long)r0) - 1) : __shfl(lab1, __ffsll((long long)r1) - 1);
+    r0 &= ~__ballot(have0 && lab0 == L);
+    r1 &= ~__ballot(have1 && lab1 == L);
+    ++uniq;
+  }
+  if (lane == 0) num_unique[b] = uniq;
+}
+
+// -------------------------------------------------------------------------------------------
+// Nearest-seed assignment: S = X Z^T on fp32 MFMA, d = 0.5(1 - S), argmin over seeds
+// (ties -> lowest seed index, torch.argmin), label = seed_labels[argmin], per-label histogram.
+// -------------------------------------------------------------------------------------------
+template <int ST>
+__global__ __launch_bounds__(HC_THREADS) void assign_kernel(const float *__restrict__ X, int n,
+                                                            const float *__restrict__ Z,
+                                                            const int *__restrict__ seed_labels, int m,
+                                                            int *__restrict__ labels, int *__restrict__ closest,
+                                                            int *__restrict__ counts) {
+  __shared__ __attribute__((aligned(16))) float Zs[ST * 16 * ZP];
+  __shared__ int slab[NLAB];
+  __shared__ int hist[NLAB];
+  const int b = blockIdx.y;
+  X += (size_t)b * n * C;
+  Z += (size_t)b * m * C;
+  seed_labels += (size_t)b * m;
+  labels += (size_t)b * n;
+  if (closest) closest += (size_t)b * n;
+  counts += (size_t)b * NLAB;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 15, q = lane >> 4;
+  for (int i = tid; i < ST * 16 * (C / 4); i += HC_THREADS) {
+    const int row = i / (C / 4), c4 = i % (C / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < m) v = *reinterpret_cast<const float4 *>(Z + (size_t)row * C + 4 * c4);
+    *reinterpret_cast<float4 *>(Zs + row * ZP + 4 * c4) = v;
+  }
+  if (tid < NLAB) {
+    slab[tid] = tid < m ? seed_labels[tid] : 0;
+    hist[tid] = 0;
+  }
+  __syncthreads();
+
+  const int ntile = (n + 15) >> 4;
+  for (int tile = blockIdx.x * (HC_THREADS / 64) + wave; tile < ntile; tile += gridDim.x * (HC_THREADS / 64)) {
+    const int pa = tile * 16 + t;
+    float4 xa[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      xa[v] = (pa < n) ? *reinterpret_cast<const float4 *>(X + (size_t)pa * C + 16 * v + 4 * q)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    float bd[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int bi[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
+#pragma unroll
+    for (int s = 0; s < ST; ++s) {
+      f32x4 S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float4 zb = *reinterpret_cast<const float4 *>(Zs + (16 * s + t) * ZP + 16 * v + 4 * q);
+        S = mfma4(xa[v].x, zb.x, S);
+        S = mfma4(xa[v].y, zb.y, S);
+        S = mfma4(xa[v].z, zb.z, S);
+        S = mfma4(xa[v].w, zb.w, S);
+      }
+      const int seed = 16 * s + t;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = 0.5f * (1.0f - S[r]);
+        if (seed < m && d < bd[r]) {  // s ascends: strict '<' keeps the lowest seed index
+          bd[r] = d;
+          bi[r] = seed;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float d = bd[r];
+      int i = bi[r];
+#define UOC_MIN_STEP(CTRL)                                   \
+  {                                                          \
+    const float od = dpp_f<CTRL>(d);                         \
+    const int oi = dpp_i<CTRL>(i);                           \
+    if (od < d || (od == d && oi < i)) {                     \
+      d = od;                                                \
+      i = oi;                                                \
+    }                                                        \
+  }
+      UOC_MIN_STEP(0xB1) UOC_MIN_STEP(0x4E) UOC_MIN_STEP(0x141) UOC_MIN_STEP(0x140)
+#undef UOC_MIN_STEP
+      bi[r] = i;
+    }
+    const int sel = (t == 0) ? bi[0] : (t == 1) ? bi[1] : (t == 2) ? bi[2] : bi[3];
+    const int p = tile * 16 + 4 * q + t;
+    if (t < 4 && p < n) {
+      const int lab = slab[sel];
+      labels[p] = lab;
+      if (closest) closest[p] = sel;
+      atomicAdd(&hist[lab], 1);
+    }
+  }
+  __syncthreads();
+  if (tid < NLAB && hist[tid]) atomicAdd(&counts[tid], hist[tid]);
+}
+
+// "assign zero to the largest cluster" (mean_shift.py:217-227): only labels in
+// range(num_unique) are counted; first maximum wins; swap 0 <-> label_max.
+__global__ __launch_bounds__(256) void relabel_swap_kernel(int *__restrict__ labels, int n,
+                                                           const int *__restrict__ counts,
+                                                           const int *__restrict__ num_unique) {
+  const int b = blockIdx.y;
+  labels += (size_t)b * n;
+  counts += (size_t)b * NLAB;
+  __shared__ int s_big;
+  if (threadIdx.x == 0) {
+    int num = num_unique[b];
+    if (num > NLAB) num = NLAB;
+    int big = 0, bc = INT_MIN;
+    for (int i = 0; i < num; ++i)
+      if (counts[i] > bc) {
+        bc = counts[i];
+        big = i;
+      }
+    s_big = big;
+  }
+  __syncthreads();
+  const int big = s_big;
+  if (big == 0) return;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const int l = labels[p];
+    if (l == 0)
+      labels[p] = big;
+    else if (l == big)
+      labels[p] = 0;
+  }
+}
+
+// ------------------------------- host side -------------------------------------------------
+struct MsWorkspace {
+  float *dmin;        // [batch][n]
+  ArgMax *part[2];    // [batch][FPS_MAX_BLOCKS] ping-pong
+  float *hc_partial;  // [batch][nblk][128][64]
+  int *counts;        // [batch][128]
+  int *num_unique;    // [batch]
+  int *seed_labels;   // [batch][128]
+  float *Z;           // [batch][128][64]
+  int hc_nblk;
+  size_t total;
+};
+
+static int hc_blocks(int batch, int n) {
+  const int ntile = (n + 15) / 16;
+  int nblk = 512 / (batch > 0 ? batch : 1);
+  if (nblk < 8) nblk = 8;
+  const int maxb = (ntile + 3) / 4;
+  if (nblk > maxb) nblk = maxb;
+  if (nblk > HC_MAX_BLOCKS) nblk = HC_MAX_BLOCKS;
+  if (nblk < 1) nblk = 1;
+  return nblk;
+}
+
+static MsWorkspace carve(void *base, int batch, int n) {
+  MsWorkspace w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    void *p = base ? (void *)((char *)base + off) : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  w.hc_nblk = hc_blocks(batch, n);
+  w.dmin = (float *)take((size_t)batch * n * sizeof(float));
+  w.part[0] = (ArgMax *)take((size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax));
+  w.part[1] = (ArgMax *)take((size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax));
+  w.hc_partial = (float *)take((size_t)batch * w.hc_nblk * NLAB * C * sizeof(float));
+  w.counts = (int *)take((size_t)batch * NLAB * sizeof(int));
+  w.num_unique = (int *)take((size_t)batch * sizeof(int));
+  w.seed_labels = (int *)take((size_t)batch * NLAB * sizeof(int));
+  w.Z = (float *)take((size_t)batch * NLAB * C * sizeof(float));
+  w.total = off;
+  return w;
+}
+
+static int check_common(const void *X, int batch, int n, int m, void *ws, size_t ws_bytes) {
+  UOC_REQUIRE(X != nullptr, "X is null");
+  UOC_REQUIRE(batch >= 1 && batch <= 65535, "batch=%d out of range [1,65535]", batch);
+  UOC_REQUIRE(n >= 1, "n=%d must be >= 1", n);
+  UOC_REQUIRE(m >= 1 && m <= UOC_MAX_SEEDS, "num_seeds=%d out of range [1,%d]", m, UOC_MAX_SEEDS);
+  UOC_REQUIRE(((uintptr_t)X & 15) == 0, "X must be 16-byte aligned");
+  const size_t need = carve(nullptr, batch, n).total;
+  UOC_REQUIRE(ws != nullptr && ws_bytes >= need, "workspace too small: %zu < %zu", ws_bytes, need);
+  UOC_REQUIRE(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
+  return UOC_OK;
+}
+
+static int fps_blocks(int n) {
+  const int nchunk = (n + 63) / 64;
+  int nblk = (nchunk + 3) / 4;
+  if (nblk > FPS_MAX_BLOCKS) nblk = FPS_MAX_BLOCKS;
+  if (nblk < 1) nblk = 1;
+  return nblk;
+}
+
+static int run_select_seeds(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
+                            int32_t *indices, const MsWorkspace &w, hipStream_t st) {
+  const int nblk = fps_blocks(n);
+  for (int s = 0; s < m; ++s) {
+    dim3 grid(nblk, batch);  // gridDim.x doubles as the partial count, so it is the same every step
+    hipLaunchKernelGGL(fps_step_kernel, grid, dim3(FPS_THREADS), 0, st, X, n, m, s, first, w.dmin, seeds, indices,
+                       w.part[(s + 1) & 1], w.part[s & 1]);
+  }
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+template <int ST>
+static void launch_hc(const float *X, int batch, int n, float *Z, int m, float kappa, int iters,
+                      const MsWorkspace &w, hipStream_t st) {
+  const size_t zbytes = (size_t)ST * 16 * ZP * sizeof(float);
+  const size_t rbytes = (size_t)2 * ST * 4 * 64 * sizeof(f32x4);
+  const size_t lds = zbytes > rbytes ? zbytes : rbytes;
+  for (int it = 0; it < iters; ++it) {
+    hipLaunchKernelGGL(hc_iter_kernel<ST>, dim3(w.hc_nblk, batch), dim3(HC_THREADS), lds, st, X, n, Z, m, kappa,
+                       w.hc_partial);
+    hipLaunchKernelGGL(hc_finalize_kernel, dim3(m, batch), dim3(256), 0, st, w.hc_partial, w.hc_nblk, ST * 16, m, Z);
+  }
+}
+
+static int run_hill_climb(const float *X, int batch, int n, float *Z, int m, float kappa, int iters,
+                          const MsWorkspace &w, hipStream_t st) {
+  switch ((m + 15) / 16) {
+    case 1: launch_hc<1>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 2: launch_hc<2>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 3: launch_hc<3>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 4: launch_hc<4>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 5: launch_hc<5>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 6: launch_hc<6>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 7: launch_hc<7>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    default: launch_hc<8>(X, batch, n, Z, m, kappa, iters, w, st); break;
+  }
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+template <int ST>
+static void launch_assign(const float *X, int batch, int n, const float *Z, const int *seed_labels, int m,
+                          int *labels, int *closest, const MsWorkspace &w, hipStream_t st) {
+  int nblk = hc_blocks(batch, n) * 2;
+  const int maxb = ((n + 15) / 16 + 3) / 4;
+  if (nblk > maxb) nblk = maxb;
+  hipLaunchKernelGGL(assign_kernel<ST>, dim3(nblk, batch), dim3(HC_THREADS), 0, st, X, n, Z, seed_labels, m, labels,
+                     closest, w.counts);
+}
+
+static int run_assign(const float *X, int batch, int n, const float *Z, const int *seed_labels,
+                      const int *num_unique, int m, int *labels, int *closest, const MsWorkspace &w,
+                      hipStream_t st) {
+  UOC_HIP_CHECK(hipMemsetAsync(w.counts, 0, (size_t)batch * NLAB * sizeof(int), st));
+  switch ((m + 15) / 16) {
+    case 1: launch_assign<1>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 2: launch_assign<2>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 3: launch_assign<3>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 4: launch_assign<4>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 5: launch_assign<5>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 6: launch_assign<6>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 7: launch_assign<7>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    default: launch_assign<8>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+  }
+  int rb = (n + 255) / 256;
+  if (rb > 512) rb = 512;
+  hipLaunchKernelGGL(relabel_swap_kernel, dim3(rb, batch), dim3(256), 0, st, labels, n, w.counts, num_unique);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+}  // namespace uoc
+
+using namespace uoc;
+
+extern "C" {
+
+size_t uoc_ms_workspace_bytes(int batch, int n, int m) {
+  (void)m;
+  if (batch < 1 || n < 1) return 0;
+  return carve(nullptr, batch, n).total;
+}
+
+int uoc_ms_select_seeds(const float *d_X, int batch, int n, int m, const int32_t *d_first_index, float *d_seeds,
+                        int32_t *d_indices, void *d_ws, size_t ws_bytes, void *stream) {
+  if (int rc = check_common(d_X, batch, n, m, d_ws, ws_bytes)) return rc;
+  UOC_REQUIRE(d_first_index && d_seeds && d_indices, "null output/first_index pointer");
+  return run_select_seeds(d_X, batch, n, m, d_first_index, d_seeds, d_indices, carve(d_ws, batch, n),
+                          (hipStream_t)stream);
+}
+
+int uoc_ms_hill_climb(const float *d_X, int batch, int n, float *d_Z, int m, float kappa, int iters, void *d_ws,
+                      size_t ws_bytes, void *stream) {
+  if (int rc = check_common(d_X, batch, n, m, d_ws, ws_bytes)) return rc;
+  UOC_REQUIRE(d_Z != nullptr && ((uintptr_t)d_Z & 15) == 0, "Z null or not 16-byte aligned");
+  UOC_REQUIRE(iters >= 0, "iters=%d must be >= 0", iters);
+  return run_hill_climb(d_X, batch, n, d_Z, m, kappa, iters, carve(d_ws, batch, n), (hipStream_t)stream);
+}
+
+int uoc_ms_seed_components(const float *d_Z, int batch, int m, float epsilon, int32_t *d_seed_labels,
+                           int32_t *d_num_unique, void *stream) {
+  UOC_REQUIRE(d_Z && d_seed_labels && d_num_unique, "null pointer");
+  UOC_REQUIRE(batch >= 1 && m >= 1 && m <= UOC_MAX_SEEDS, "batch=%d m=%d out of range", batch, m);
+  hipLaunchKernelGGL(seed_cc_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, d_Z, m, epsilon, d_seed_labels,
+                     d_num_unique);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+int uoc_ms_assign(const float *d_X, int batch, int n, const float *d_Z, const int32_t *d_seed_labels,
+                  const int32_t *d_num_unique, int m, int32_t *d_labels, int32_t *d_closest, void *d_ws,
+                  size_t ws_bytes, void *stream) {
+  if (int rc = check_common(d_X, batch, n, m, d_ws, ws_bytes)) return rc;
+  UOC_REQUIRE(d_Z && d_seed_labels && d_num_unique && d_labels, "null pointer");
+  return run_assign(d_X, batch, n, d_Z, d_seed_labels, d_num_unique, m, d_labels, d_closest, carve(d_ws, batch, n),
+                    (hipStream_t)stream);
+}
+
+int uoc_ms_cluster(const float *d_X, int batch, int n, int m, float kappa, int iters, float epsilon,
+                   const int32_t *d_first_index, int32_t *d_labels, int32_t *d_indices, float *d_Z_out,
+                   int32_t *d_seed_labels_out, void *d_ws, size_t ws_bytes, void *stream) {
+  if (int rc = check_common(d_X, batch, n, m, d_ws, ws_bytes)) return rc;
+  UOC_REQUIRE(d_first_index && d_labels && d_indices, "null pointer");
+  UOC_REQUIRE(iters >= 0, "iters=%d must be >= 0", iters);
+  hipStream_t st = (hipStream_t)stream;
+  MsWorkspace w = carve(d_ws, batch, n);
+  float *Z = d_Z_out ? d_Z_out : w.Z;
+  int *sl = d_seed_labels_out ? d_seed_labels_out : w.seed_labels;
+  if (int rc = run_select_seeds(d_X, batch, n, m, d_first_index, Z, d_indices, w, st)) return rc;
+  if (int rc = run_hill_climb(d_X, batch, n, Z, m, kappa, iters, w, st)) return rc;
+  hipLaunchKernelGGL(seed_cc_kernel, dim3(batch), dim3(64), 0, st, Z, m, epsilon, sl, w.num_unique);
+  UOC_LAUNCH_CHECK();
+  return run_assign(d_X, batch, n, Z, sl, w.num_unique, m, d_labels, nullptr, w, st);
+}
+
+}  // extern "C"

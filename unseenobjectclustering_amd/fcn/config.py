@@ -1,0 +1,53 @@
+"""Process-global config object `cfg` — the subset of the reference's lib/fcn/config.py that the
+inference hot path reads, with the values the RGB-D `add` / cosine experiment
+config sets (experiments/cfgs/seg_resnet34_8s_embedding_cosine_rgbd_add_tabletop.yml).
+
+The reference's default EMBEDDING_METRIC is 'euclidean' (config.py:261) and every shipped
+experiment overrides it to 'cosine'; this build implements the cosine path only and raises if
+asked for anything else.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+cfg = AttrDict()
+cfg.INPUT = "RGBD"                     # config.py:30
+cfg.MODE = "TEST"
+cfg.RNG_SEED = 3                       # config.py:379
+cfg.PIXEL_MEANS = np.array([[[102.9801, 115.9465, 122.7717]]])   # config.py:376 (BGR)
+cfg.gpu_id = 0
+cfg.device = None                      # set by the driver (tools/test_images.py:157-158)
+
+cfg.TRAIN = AttrDict()
+cfg.TRAIN.NUM_UNITS = 64               # config.py:165
+cfg.TRAIN.FUSION_TYPE = "add"          # config.py:92
+cfg.TRAIN.SYN_CROP_SIZE = 224          # config.py:129
+cfg.TRAIN.EMBEDDING_PRETRAIN = False
+cfg.TRAIN.EMBEDDING_METRIC = "cosine"  # yml:56 (code default 'euclidean' is not implemented here)
+cfg.TRAIN.EMBEDDING_NORMALIZATION = True
+cfg.TRAIN.EMBEDDING_ALPHA = 0.02       # config.py:254 ; epsilon = 2*alpha (mean_shift.py:123)
+
+cfg.TEST = AttrDict()
+cfg.TEST.VISUALIZE = False             # config.py:319
+
+
+def require_supported():
+    """The HIP path implements exactly one configuration; fail loudly on anything else."""
+    if cfg.TRAIN.EMBEDDING_METRIC != "cosine":
+        raise NotImplementedError("only cfg.TRAIN.EMBEDDING_METRIC='cosine' is implemented on gfx950")
+    if cfg.INPUT != "RGBD" or cfg.TRAIN.FUSION_TYPE != "add":
+        raise NotImplementedError("only cfg.INPUT='RGBD' with cfg.TRAIN.FUSION_TYPE='add' is implemented")
+    if not cfg.TRAIN.EMBEDDING_NORMALIZATION:
+        raise NotImplementedError("EMBEDDING_NORMALIZATION=False is not implemented")

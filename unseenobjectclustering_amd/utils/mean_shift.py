@@ -1,0 +1,147 @@
+"""Host-side mirror of the reference's lib/utils/mean_shift.py (cosine metric), backed by the
+HIP kernels in csrc/meanshift.hip through the C ABI (include/uoc_hip.h).
+
+Same names, argument meaning and return types as the reference:
+    mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric='cosine')
+        -> (cluster_labels [n] int64, selected_indices [num_seeds] int64)      mean_shift.py:192
+    select_smart_seeds / seed_hill_climbing_ball / connected_components / mean_shift_with_seeds
+
+The first seed of every call is drawn with np.random.randint(0, n) exactly like the reference
+(mean_shift.py:155), on the host, and handed to the kernels.  There is no CPU fallback: tensors
+must live on a ROCm device and libuoc_hip.so must be built.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import _native
+from ..fcn.config import cfg
+
+EMBED_DIM = 64
+_ws_cache = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    key = (device.type, device.index)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def _check_points(X: torch.Tensor, what="X") -> torch.Tensor:
+    if not X.is_cuda:
+        raise _native.NativeError(f"{what} must be on a ROCm device (no CPU fallback); got {X.device}")
+    if X.dtype != torch.float32:
+        raise TypeError(f"{what} must be float32, got {X.dtype}")
+    if X.shape[-1] != EMBED_DIM:
+        raise NotImplementedError(f"kernels are specialised for d={EMBED_DIM}; got d={X.shape[-1]}")
+    return X.contiguous()
+
+
+def _require_cosine(metric):
+    if metric != "cosine":
+        raise NotImplementedError("only metric='cosine' is implemented on gfx950")
+
+
+def cluster_batch(X: torch.Tensor, first_index, kappa: float = 20.0, num_seeds: int = 100, max_iters: int = 10,
+                  epsilon: float = None, return_parts: bool = False):
+    """Cluster B independent fields in one set of launches.
+
+    X [B, n, 64] float32 unit rows (pixel-major), first_index: B ints.
+    Returns labels [B, n] int32 and indices [B, num_seeds] int32 (device tensors); with
+    return_parts also the converged seeds Z [B, m, 64] and their labels [B, m].
+    """
+    X = _check_points(X)
+    assert X.dim() == 3
+    B, n, _ = X.shape
+    if epsilon is None:
+        epsilon = 2 * cfg.TRAIN.EMBEDDING_ALPHA
+    dev = X.device
+    L = _native.lib()
+    first = torch.as_tensor(np.asarray(first_index, dtype=np.int32).reshape(B)).to(dev)
+    labels = torch.empty((B, n), dtype=torch.int32, device=dev)
+    indices = torch.empty((B, num_seeds), dtype=torch.int32, device=dev)
+    Z = torch.empty((B, num_seeds, EMBED_DIM), dtype=torch.float32, device=dev)
+    seed_labels = torch.empty((B, num_seeds), dtype=torch.int32, device=dev)
+    nbytes = L.uoc_ms_workspace_bytes(B, n, num_seeds)
+    ws = _workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        rc = L.uoc_ms_cluster(_native.ptr(X), B, n, num_seeds, float(kappa), int(max_iters), float(epsilon),
+                              _native.ptr(first), _native.ptr(labels), _native.ptr(indices), _native.ptr(Z),
+                              _native.ptr(seed_labels), _native.ptr(ws), ws.numel(), _native.stream_ptr(dev))
+    _native.check(rc, "uoc_ms_cluster")
+    if return_parts:
+        return labels, indices, Z, seed_labels
+    return labels, indices
+
+
+def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine"):
+    """mean_shift.py:192-229.  X [n, d] unit rows on the GPU -> (labels [n] int64, indices [m] int64)."""
+    _require_cosine(metric)
+    n = X.shape[0]
+    first = np.random.randint(0, n)          # mean_shift.py:155 — same global-RNG draw as the reference
+    labels, indices = cluster_batch(X.unsqueeze(0), [first], kappa, num_seeds, max_iters)
+    return labels[0].long(), indices[0].long().cpu()
+
+
+def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=None, num_init_seeds=None,
+                       metric="cosine"):
+    """mean_shift.py:128-189 (init_seeds continuation is not used on the hot path and not implemented)."""
+    _require_cosine(metric)
+    if init_seeds is not None:
+        raise NotImplementedError("init_seeds continuation is not part of the inference hot path")
+    X = _check_points(X)
+    n = X.shape[0]
+    dev = X.device
+    L = _native.lib()
+    first = torch.tensor([np.random.randint(0, n)], dtype=torch.int32).to(dev)
+    seeds = torch.empty((num_seeds, EMBED_DIM), dtype=torch.float32, device=dev)
+    indices = torch.empty((num_seeds,), dtype=torch.int32, device=dev)
+    ws = _workspace(dev, L.uoc_ms_workspace_bytes(1, n, num_seeds))
+    with torch.cuda.device(dev):
+        rc = L.uoc_ms_select_seeds(_native.ptr(X), 1, n, num_seeds, _native.ptr(first), _native.ptr(seeds),
+                                   _native.ptr(indices), _native.ptr(ws), ws.numel(), _native.stream_ptr(dev))
+    _native.check(rc, "uoc_ms_select_seeds")
+    if return_selected_indices:
+        return seeds, indices.long().cpu()
+    return (seeds,)
+
+
+def seed_hill_climbing_ball(X, Z, kappa, max_iters=10, metric="cosine"):
+    """mean_shift.py:79-109.  Returns the updated seeds (a new tensor, Z is not modified)."""
+    _require_cosine(metric)
+    X = _check_points(X)
+    Zc = _check_points(Z, "Z").clone()
+    n, m = X.shape[0], Zc.shape[0]
+    L = _native.lib()
+    ws = _workspace(X.device, L.uoc_ms_workspace_bytes(1, n, m))
+    with torch.cuda.device(X.device):
+        rc = L.uoc_ms_hill_climb(_native.ptr(X), 1, n, _native.ptr(Zc), m, float(kappa), int(max_iters),
+                                 _native.ptr(ws), ws.numel(), _native.stream_ptr(X.device))
+    _native.check(rc, "uoc_ms_hill_climb")
+    return Zc
+
+
+def connected_components(Z, epsilon, metric="cosine"):
+    """mean_shift.py:41-76.  Z [m, d] -> [m] int64 labels (CPU tensor, like the reference)."""
+    _require_cosine(metric)
+    Zc = _check_points(Z, "Z")
+    m = Zc.shape[0]
+    L = _native.lib()
+    out = torch.empty((m,), dtype=torch.int32, device=Zc.device)
+    nu = torch.empty((1,), dtype=torch.int32, device=Zc.device)
+    with torch.cuda.device(Zc.device):
+        rc = L.uoc_ms_seed_components(_native.ptr(Zc), 1, m, float(epsilon), _native.ptr(out), _native.ptr(nu),
+                                      _native.stream_ptr(Zc.device))
+    _native.check(rc, "uoc_ms_seed_components")
+    return out.long().cpu()
+
+
+def mean_shift_with_seeds(X, Z, kappa, max_iters=10, metric="cosine"):
+    """mean_shift.py:112-125: hill climbing then seed connected components (eps = 2*alpha)."""
+    Znew = seed_hill_climbing_ball(X, Z, kappa, max_iters=max_iters, metric=metric)
+    labels = connected_components(Znew, 2 * cfg.TRAIN.EMBEDDING_ALPHA, metric=metric)
+    return labels, Znew
