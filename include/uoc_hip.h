@@ -71,6 +71,34 @@ int uoc_ms_cluster(const float *d_X, int batch, int n, int m, float kappa, int i
                    const int32_t *d_first_index, int32_t *d_labels, int32_t *d_indices,
                    float *d_Z_out, int32_t *d_seed_labels_out, void *d_ws, size_t ws_bytes, void *stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * RGB-D ResNet34-8s embedding network — replaces SEGNET.forward (lib/networks/SEG.py:88-119,
+ * RGBD/'add' branch) with its two Resnet34_8s backbones (resnet_dilated.py:287-327,
+ * resnet.py:116-270).  Activations NHWC fp32, convolutions on fp32 MFMA, BatchNorm folded.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct uoc_net uoc_net;
+
+int uoc_net_create(uoc_net **out);
+int uoc_net_destroy(uoc_net *net);
+/* One state-dict entry by its reference key ("fcn.resnet34_8s.layer1.0.conv1.weight", ...;
+ * SEG.py:130-159 contract), HOST fp32 memory, copied. */
+int uoc_net_load_param(uoc_net *net, const char *name, const float *host_data, size_t numel);
+/* Checks that every parameter is present, folds BN (eps 1e-5), re-lays weights out as
+ * [tap][cout][cin] and uploads them to the CURRENT device. */
+int uoc_net_finalize(uoc_net *net);
+size_t uoc_net_workspace_bytes(const uoc_net *net, int B, int H, int W);
+/* d_rgb, d_xyz: [B][3][H][W] fp32 NCHW (what test_sample hands the network, test_dataset.py:247);
+ * d_embed: [B][H*W][64] pixel-major unit-norm embeddings. */
+int uoc_net_forward(uoc_net *net, const float *d_rgb, const float *d_xyz, int B, int H, int W, float *d_embed,
+                    void *d_ws, size_t ws_bytes, void *stream);
+
+/* Single fused conv (+bias +residual +ReLU), NHWC, weights [K*K][Cout][Cin]; K in {1,3}.
+ * Cin % 32 == 0, Cout % 64 == 0.  Exposed for unit tests of the conv kernel. */
+int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, const float *d_res, float *d_out,
+                    int B, int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu,
+                    void *stream);
+
 #ifdef __cplusplus
 }
 #endif

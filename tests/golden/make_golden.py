@@ -49,6 +49,44 @@ def make_meanshift(ref):
     np.savez_compressed(os.path.join(HERE, "meanshift.npz"), **out)
 
 
+def sample_positions(seed, n, count):
+    return np.sort(np.random.default_rng(seed).choice(n, size=min(count, n), replace=False)).astype(np.int64)
+
+
+BACKBONE_CASES = {
+    # name -> (weight seed, frame seeds, H, W, num sampled pixels (0 = keep everything))
+    "tiny_64x64":   dict(wseed=1, frames=[7], H=64, W=64, samples=0),
+    "odd_72x104":   dict(wseed=2, frames=[8], H=72, W=104, samples=0),
+    "crops_224":    dict(wseed=2, frames=[4, 5], H=224, W=224, samples=1024),
+    "full_480x640": dict(wseed=1, frames=[1], H=480, W=640, samples=2048),
+}
+
+
+def make_backbone(ref):
+    import contextlib
+    import io
+    out = {}
+    for name, c in BACKBONE_CASES.items():
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.synthetic_state_dict(c["wseed"]).items()}
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = ref.networks.__dict__["seg_resnet34_8s_embedding"](2, 64, sd).eval()
+        frames = [synth.rgbd_frame(s, c["H"], c["W"], 4) for s in c["frames"]]
+        img = torch.from_numpy(np.concatenate([f["image_color"] for f in frames]))
+        dep = torch.from_numpy(np.concatenate([f["depth"] for f in frames]))
+        with torch.no_grad():
+            feat = net(img, None, dep)                       # [B,64,H,W]
+        B = feat.shape[0]
+        flat = feat.permute(0, 2, 3, 1).reshape(B, -1, 64).numpy()
+        if c["samples"]:
+            pos = sample_positions(99, flat.shape[1], c["samples"])
+            out[name + "/pos"] = pos
+            out[name + "/embed"] = flat[:, pos].astype(np.float32)
+        else:
+            out[name + "/embed"] = flat.astype(np.float32)
+        print(name, feat.shape, "norm check", float(feat.norm(dim=1).mean()), flush=True)
+    np.savez_compressed(os.path.join(HERE, "backbone.npz"), **out)
+
+
 def main():
     assert ref_harness.available(), "reference tree not present: golden vectors can only be made in the build container"
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -56,6 +94,8 @@ def main():
     torch.manual_seed(0)
     if what in ("meanshift", "all"):
         make_meanshift(ref)
+    if what in ("backbone", "all"):
+        make_backbone(ref)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,113 @@
+"""GPU parity of the HIP ResNet34-8s RGB-D embedding network.
+
+(a) the fp32-MFMA conv kernel against torch CPU conv2d (plain fp32 reference of the same op),
+(b) the whole two-branch network against golden embeddings captured from the reference's own
+    SEGNET.forward (tests/golden/backbone.npz) — tolerance 1e-3 absolute as north_star states
+    (embeddings are unit-norm, so absolute == relative to the vector scale),
+(c) the CPU oracle on a fresh seeded input.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import backbone_oracle as BO
+from unseenobjectclustering_amd import _native, networks, synth
+
+pytestmark = pytest.mark.gpu
+EMBED_TOL = 1e-3
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, K, stride, dil, residual, relu
+    (1, 30, 40, 64, 64, 3, 1, 1, True, True),
+    (2, 31, 27, 64, 128, 3, 2, 1, False, True),
+    (1, 20, 24, 128, 256, 3, 1, 2, True, True),
+    (1, 15, 20, 256, 512, 3, 1, 4, False, True),
+    (1, 15, 20, 512, 512, 3, 1, 4, True, True),
+    (2, 33, 17, 64, 128, 1, 2, 1, False, False),
+    (1, 60, 80, 512, 64, 1, 1, 1, False, False),
+    (3, 9, 7, 32, 64, 3, 1, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_kernel_vs_torch_cpu(device, case):
+    B, H, W, Cin, Cout, K, stride, dil, use_res, relu = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / np.sqrt(Cin * K * K)
+    b = torch.randn(Cout, generator=g)
+    pad = dil if K == 3 else 0
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dil)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(device)                     # NHWC
+    wd = w.permute(2, 3, 0, 1).reshape(K * K, Cout, Cin).contiguous().to(device)   # [tap][cout][cin]
+    bd = b.to(device)
+    rd = res.permute(0, 2, 3, 1).contiguous().to(device) if res is not None else None
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    out = torch.empty((B, Ho, Wo, Cout), device=device)
+    L = _native.lib()
+    rc = L.uoc_conv2d_nhwc(_native.ptr(xd), _native.ptr(wd), _native.ptr(bd), _native.ptr(rd), _native.ptr(out),
+                           B, H, W, Cin, Cout, K, stride, dil, pad, int(relu), _native.stream_ptr(device))
+    _native.check(rc, "uoc_conv2d_nhwc")
+    got = out.cpu().permute(0, 3, 1, 2)
+    err = (got - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+
+
+def _net(wseed, device):
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.synthetic_state_dict(wseed).items()}
+    net = networks.seg_resnet34_8s_embedding(2, 64, sd)
+    return net.eval(), sd
+
+
+GOLDEN_CASES = {
+    "tiny_64x64": dict(wseed=1, frames=[7], H=64, W=64),
+    "odd_72x104": dict(wseed=2, frames=[8], H=72, W=104),
+    "crops_224": dict(wseed=2, frames=[4, 5], H=224, W=224),
+    "full_480x640": dict(wseed=1, frames=[1], H=480, W=640),
+}
+
+
+@pytest.mark.parametrize("name", list(GOLDEN_CASES))
+def test_network_matches_reference_golden(golden_dir, device, name):
+    g = np.load(os.path.join(golden_dir, "backbone.npz"))
+    c = GOLDEN_CASES[name]
+    net, _ = _net(c["wseed"], device)
+    frames = [synth.rgbd_frame(s, c["H"], c["W"], 4) for s in c["frames"]]
+    img = torch.from_numpy(np.concatenate([f["image_color"] for f in frames])).to(device)
+    dep = torch.from_numpy(np.concatenate([f["depth"] for f in frames])).to(device)
+    feat = net(img, None, dep)
+    assert feat.shape == (len(frames), 64, c["H"], c["W"])
+    flat = feat.permute(0, 2, 3, 1).reshape(len(frames), -1, 64).cpu().numpy()
+    if name + "/pos" in g:
+        flat = flat[:, g[name + "/pos"]]
+    err = np.abs(flat - g[name + "/embed"]).max()
+    assert err < EMBED_TOL, err
+    assert np.abs(np.linalg.norm(flat, axis=2) - 1).max() < 1e-5
+
+
+def test_network_vs_oracle_fresh_input(device):
+    net, sd = _net(5, device)
+    fr = synth.rgbd_frame(12, 120, 88, 3)
+    img, dep = torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"])
+    want = BO.segnet_forward(sd, img, dep)
+    got = net(img.to(device), None, dep.to(device)).cpu()
+    assert (got - want).abs().max().item() < EMBED_TOL
+
+
+def test_network_interface(device):
+    net, sd = _net(1, device)
+    assert set(net.state_dict().keys()) == set(sd.keys())
+    with pytest.raises(_native.NativeError):
+        net(torch.zeros(1, 3, 64, 64), None, torch.zeros(1, 3, 64, 64))   # CPU tensors: no fallback
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(torch.zeros(1, 3, 64, 64, device=device), None, torch.zeros(1, 3, 64, 64, device=device))

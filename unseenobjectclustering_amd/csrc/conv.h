@@ -1,0 +1,30 @@
+// Internal interface of the conv / pooling / head kernels (csrc/conv.hip, csrc/head.hip).
+#pragma once
+#include "common.h"
+
+namespace uoc {
+
+// One convolution over G independent groups (= the RGB and the XYZ branch, which have their
+// own weights).  Activations are NHWC fp32; weights are [G][taps][Cout][Kc] with BatchNorm
+// already folded in (Kc = Cin, or 32 for the stem's 8-pixel x 4-channel rows).
+struct ConvParams {
+  const float *in;    // [G][B][H][W][Cin]
+  const float *w;     // [G][T][Cout][Kc]
+  const float *bias;  // [G][Cout]
+  const float *res;   // [G][B][Ho][Wo][Cout] or nullptr
+  float *out;         // [G][B][Ho][Wo][Cout]
+  int G, B, H, W, Cin, Ho, Wo, Cout;
+  int KH, KW, stride, dil, pad, relu;
+  int stem;           // 1: 7x7 s2 p3 conv over NHWC4 input, K-chunk = one kernel row
+};
+
+int launch_conv(const ConvParams &p, hipStream_t st);
+
+// NCHW [B][3][H][W] -> NHWC4 [B][H][W][4] (4th channel = 0)
+int launch_nchw3_to_nhwc4(const float *in, float *out, int B, int H, int W, hipStream_t st);
+// 3x3 s2 p1 max pooling, NHWC, C % 4 == 0; `n_img` images
+int launch_maxpool3x3s2(const float *in, float *out, int n_img, int H, int W, int C, int Ho, int Wo, hipStream_t st);
+// embed[b][p][:] = normalize(bilinear_up(a[b] + c[b]))  (align_corners=True), a,c: [B][h][w][64]
+int launch_head(const float *fa, const float *fb, float *embed, int B, int h, int w, int H, int W, hipStream_t st);
+
+}  // namespace uoc

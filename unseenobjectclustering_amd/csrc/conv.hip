@@ -1,0 +1,392 @@
+// fp32 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_16x16x4_f32) with the
+// BatchNorm shift, residual add and ReLU fused into the epilogue, plus the small layout /
+// pooling kernels of the ResNet34-8s backbone.
+//
+// Replaces the cuDNN/ATen calls behind /root/reference/lib/networks/resnet.py:
+//   conv3x3 (+dilation, stride)  :24-41,57-73   conv1x1 downsample :215-219
+//   stem conv7x7 s2 p3           :141-144       MaxPool2d(3,2,1)   :145
+//   fc = Conv2d(512, 64, 1)      resnet_dilated.py:303
+//
+// GEMM view: D[cout][pixel] = sum_k W[cout][k] * A[pixel][k], k = (tap, cin).  NHWC activations
+// make every K-chunk (one tap, 32 input channels) a contiguous 128-byte row per pixel, and the
+// weights are stored [tap][cout][cin] so the weight rows have the same shape.  Both operands
+// are staged through LDS (double-buffered, register-staged so the row pitch can be padded) and
+// read back as ds_read_b128 MFMA fragments; the K index inside a chunk is permuted
+// (lane q supplies k = 16h + 4q + e) so one b128 read feeds four MFMA steps.
+// With weights as the MFMA "A" operand, each lane ends up holding 4 CONSECUTIVE output channels
+// of one pixel, so the epilogue is float4 loads/stores in NHWC.
+#include "conv.h"
+
+#include <stdlib.h>
+
+namespace uoc {
+
+constexpr int BK = 32;   // K-chunk (floats)
+constexpr int BKP = 36;  // padded LDS row pitch
+
+__device__ __forceinline__ f32x4 mfma4c(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
+__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvParams p, int ntiles) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int RPP = NT / 8;  // rows staged per pass (8 float4 per 32-float row)
+  constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
+  static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile must be a multiple of 16x16");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int g = blockIdx.y;
+  const int nt = blockIdx.x % ntiles, mt = blockIdx.x / ntiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int HoWo = p.Ho * p.Wo;
+  const int M = p.B * HoWo;
+  const int Kc = STEM ? 32 : p.Cin;
+  const int T = STEM ? p.KH : p.KH * p.KW;
+  const int cpt = STEM ? 1 : p.Cin / BK;  // chunks per tap
+  const int nk = T * cpt;
+
+  const float *__restrict__ in = p.in + (size_t)g * p.B * p.H * p.W * p.Cin;
+  const float *__restrict__ w = p.w + (size_t)g * T * p.Cout * Kc;
+  const float *__restrict__ bias = p.bias + (size_t)g * p.Cout;
+  const float *__restrict__ res = p.res ? p.res + (size_t)g * M * p.Cout : nullptr;
+  float *__restrict__ out = p.out + (size_t)g * M * p.Cout;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int t = lane & 15, q = lane >> 4;
+  const int lrow = tid >> 3, lcol = tid & 7;
+
+  int a_iy0[APASS], a_ix0[APASS], a_base[APASS];
+#pragma unroll
+  for (int j = 0; j < APASS; ++j) {
+    const int row = lrow + j * RPP;
+    const int m = m0 + row;
+    if (row < BM && m < M) {
+      const int b = m / HoWo;
+      const int r = m - b * HoWo;
+      const int oy = r / p.Wo, ox = r - oy * p.Wo;
+      a_iy0[j] = oy * p.stride - p.pad;
+      a_ix0[j] = ox * p.stride - p.pad;
+      a_base[j] = b * p.H * p.W * p.Cin;
+    } else {
+      a_iy0[j] = -(1 << 28);  // never in range
+      a_ix0[j] = 0;
+      a_base[j] = 0;
+    }
+  }
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // kc = -1 is the prologue (stage chunk 0 only); afterwards: global loads of chunk kc+1 fly under
+  // the MFMAs of chunk kc, are written to the other LDS stage, one barrier per chunk.
+  float4 ra[APASS], rb[BPASS];
+#pragma unroll
+  for (int j = 0; j < APASS; ++j) ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < BPASS; ++j) rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int kc = -1; kc < nk; ++kc) {
+    const bool more = kc + 1 < nk;
+    if (more) {
+      const int kn = kc + 1;
+      const int tap = kn / cpt;
+      const int c0 = (kn - tap * cpt) * BK;
+      const int kh = STEM ? tap : tap / p.KW;
+      const int kw = STEM ? 0 : tap - kh * p.KW;
+#pragma unroll
+      for (int j = 0; j < APASS; ++j) {
+        const int iy = a_iy0[j] + kh * p.dil;
+        const int ix = a_ix0[j] + (STEM ? lcol : kw * p.dil);
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float *src = in + a_base[j] + (iy * p.W + ix) * p.Cin + (STEM ? 0 : c0 + 4 * lcol);
+        ra[j] = ok ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j) {
+        int row = lrow + j * RPP;
+        if (row >= BN) row = BN - 1;  // harmless duplicate load; the LDS store is guarded
+        rb[j] = *reinterpret_cast<const float4 *>(w + ((size_t)tap * p.Cout + n0 + row) * Kc + c0 + 4 * lcol);
+      }
+    }
+    if (kc >= 0) {
+      const float *As = smem + (kc & 1) * (BM + BN) * BKP;
+      const float *Ws = As + BM * BKP;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float4 wa[TN], xb[TM];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          wa[j] = *reinterpret_cast<const float4 *>(Ws + (wn * WN + 16 * j + t) * BKP + 16 * h + 4 * q);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          xb[i] = *reinterpret_cast<const float4 *>(As + (wm * WM + 16 * i + t) * BKP + 16 * h + 4 * q);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[j][i] = mfma4c(wa[j].x, xb[i].x, acc[j][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[j][i] = mfma4c(wa[j].y, xb[i].y, acc[j][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[j][i] = mfma4c(wa[j].z, xb[i].z, acc[j][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i) acc[j][i] = mfma4c(wa[j].w, xb[i].w, acc[j][i]);
+      }
+    }
+    if (more) {
+      float *As = smem + ((kc + 1) & 1) * (BM + BN) * BKP;
+      float *Ws = As + BM * BKP;
+#pragma unroll
+      for (int j = 0; j < APASS; ++j) {
+        const int row = lrow + j * RPP;
+        if (row < BM) *reinterpret_cast<float4 *>(As + row * BKP + 4 * lcol) = ra[j];
+      }
+#pragma unroll
+      for (int j = 0; j < BPASS; ++j) {
+        const int row = lrow + j * RPP;
+        if (row < BN) *reinterpret_cast<float4 *>(Ws + row * BKP + 4 * lcol) = rb[j];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: + folded-BN shift, + residual, ReLU; lane holds 4 consecutive couts of a pixel
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn * WN + 16 * j + 4 * q;
+    const float4 bv = *reinterpret_cast<const float4 *>(bias + co);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WM + 16 * i + t;
+      if (m < M) {
+        float4 v = make_float4(acc[j][i][0] + bv.x, acc[j][i][1] + bv.y, acc[j][i][2] + bv.z, acc[j][i][3] + bv.w);
+        if (res) {
+          const float4 rv = *reinterpret_cast<const float4 *>(res + (size_t)m * p.Cout + co);
+          v.x += rv.x;
+          v.y += rv.y;
+          v.z += rv.z;
+          v.w += rv.w;
+        }
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4 *>(out + (size_t)m * p.Cout + co) = v;
+      }
+    }
+  }
+}
+
+// ---- tile configurations ---------------------------------------------------------------
+struct TileCfg {
+  int BM, BN, threads;
+  float penalty;  // relative per-flop cost of the tile shape (smaller wave tiles re-read more LDS)
+};
+static const TileCfg kCfgs[] = {
+    {160, 128, 512, 1.00f},  // 0: 2x4 waves, wave tile 80x32
+    {80, 128, 512, 1.06f},   // 1: 1x8 waves, wave tile 80x16
+    {160, 64, 512, 1.06f},   // 2: 2x4 waves, wave tile 80x16
+    {80, 64, 256, 1.12f},    // 3: 1x4 waves, wave tile 80x16
+};
+constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
+constexpr int kNumCU = 256;
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
+static int launch_cfg(const ConvParams &p, hipStream_t st) {
+  const int M = p.B * p.Ho * p.Wo;
+  const int mtiles = (M + BM - 1) / BM, ntiles = p.Cout / BN;
+  const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, STEM>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, STEM>), dim3(mtiles * ntiles, p.G),
+                     dim3(WAVES_M * WAVES_N * 64), lds, st, p, ntiles);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+static int pick_cfg(const ConvParams &p) {
+  static int forced = -2;
+  if (forced == -2) {
+    const char *e = getenv("UOC_CONV_CFG");
+    forced = e ? atoi(e) : -1;
+  }
+  const int M = p.B * p.Ho * p.Wo;
+  if (forced >= 0 && forced < kNumCfg && p.Cout % kCfgs[forced].BN == 0) return forced;
+  int best = -1;
+  double best_cost = 0;
+  for (int c = 0; c < kNumCfg; ++c) {
+    if (p.Cout % kCfgs[c].BN) continue;
+    const long blocks = (long)((M + kCfgs[c].BM - 1) / kCfgs[c].BM) * (p.Cout / kCfgs[c].BN) * p.G;
+    const long rounds = (blocks + kNumCU - 1) / kNumCU;
+    const double cost = (double)rounds * kCfgs[c].BM * kCfgs[c].BN * kCfgs[c].penalty;
+    if (best < 0 || cost < best_cost) {
+      best = c;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
+int launch_conv(const ConvParams &p, hipStream_t st) {
+  UOC_REQUIRE(p.in && p.w && p.bias && p.out, "conv: null pointer");
+  UOC_REQUIRE(p.G >= 1 && p.B >= 1 && p.H >= 1 && p.W >= 1, "conv: bad shape");
+  UOC_REQUIRE((long)p.B * p.H * p.W * p.Cin < (1l << 31) && (long)p.B * p.Ho * p.Wo * p.Cout < (1l << 31),
+              "conv: tensor too large for 32-bit indexing");
+  if (p.stem) {
+    UOC_REQUIRE(p.Cin == 4 && p.KH == 7 && p.KW == 7 && p.stride == 2 && p.pad == 3 && p.dil == 1 && p.Cout == 64,
+                "conv: stem path is 7x7 s2 p3, NHWC4 -> 64 only");
+    return launch_cfg<160, 64, 2, 4, true>(p, st);
+  }
+  UOC_REQUIRE(p.Cin % BK == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, BK);
+  UOC_REQUIRE(p.Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", p.Cout);
+  switch (pick_cfg(p)) {
+    case 0: return launch_cfg<160, 128, 2, 4, false>(p, st);
+    case 1: return launch_cfg<80, 128, 1, 8, false>(p, st);
+    case 2: return launch_cfg<160, 64, 2, 4, false>(p, st);
+    case 3: return launch_cfg<80, 64, 1, 4, false>(p, st);
+  }
+  set_error("conv: no tile configuration for Cout=%d", p.Cout);
+  return UOC_EINVAL;
+}
+
+// ---- NCHW(3) -> NHWC4 ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                             int HW, int total) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int b = i / HW, p = i - b * HW;
+    const float *src = in + (size_t)b * 3 * HW + p;
+    *reinterpret_cast<float4 *>(out + (size_t)i * 4) = make_float4(src[0], src[HW], src[2 * HW], 0.f);
+  }
+}
+
+int launch_nchw3_to_nhwc4(const float *in, float *out, int B, int H, int W, hipStream_t st) {
+  const int total = B * H * W;
+  int blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks), dim3(256), 0, st, in, out, H * W, total);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+// ---- MaxPool2d(kernel 3, stride 2, padding 1), NHWC ------------------------------------
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restrict__ in, float *__restrict__ out,
+                                                           int H, int W, int C4, int Ho, int Wo, int total) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int c4 = i % C4;
+    int r = i / C4;
+    const int ox = r % Wo;
+    r /= Wo;
+    const int oy = r % Ho;
+    const int b = r / Ho;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = 2 * oy - 1 + dy;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = 2 * ox - 1 + dx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const float4 v = *reinterpret_cast<const float4 *>(in + (((size_t)b * H + iy) * W + ix) * C4 * 4 + c4 * 4);
+        m.x = fmaxf(m.x, v.x);
+        m.y = fmaxf(m.y, v.y);
+        m.z = fmaxf(m.z, v.z);
+        m.w = fmaxf(m.w, v.w);
+      }
+    }
+    *reinterpret_cast<float4 *>(out + (size_t)i * 4) = m;
+  }
+}
+
+int launch_maxpool3x3s2(const float *in, float *out, int n_img, int H, int W, int C, int Ho, int Wo, hipStream_t st) {
+  UOC_REQUIRE(C % 4 == 0, "maxpool: C %% 4 != 0");
+  const int total = n_img * Ho * Wo * (C / 4);
+  int blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, st, in, out, H, W, C / 4, Ho, Wo, total);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+// ---- fused head: (branch a + branch b) -> x8 bilinear (align_corners=True) -> L2 normalise ---
+// Upsampling is linear, so the two branches are added at 1/8 resolution first
+// (resnet_dilated.py:325 per branch, SEG.py:106-108 add, SEG.py:113-114 normalise).
+// 16 lanes own one output pixel (float4 of channels each); a wave writes 1 KiB contiguous.
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ fa, const float *__restrict__ fb,
+                                                   float *__restrict__ embed, int B, int h, int w, int H, int W,
+                                                   float sy, float sx) {
+  const int lane = threadIdx.x & 63;
+  const int t = lane & 15, g = lane >> 4;
+  const int HW = H * W;
+  const long total = (long)B * HW;
+  const long gw = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long p4 = gw * 4; p4 < total; p4 += nw * 4) {
+    const long pix = p4 + g;
+    if (pix >= total) continue;
+    const int b = (int)(pix / HW);
+    const int r = (int)(pix - (long)b * HW);
+    const int oy = r / W, ox = r - oy * W;
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const size_t base = (size_t)b * h * w * 64 + 4 * t;
+    auto ld = [&](int y, int x) {
+      const size_t o = base + ((size_t)y * w + x) * 64;
+      const float4 u = *reinterpret_cast<const float4 *>(fa + o);
+      const float4 v = *reinterpret_cast<const float4 *>(fb + o);
+      return make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+    };
+    const float4 v00 = ld(y0, x0), v01 = ld(y0, x1), v10 = ld(y1, x0), v11 = ld(y1, x1);
+    float4 o;
+    o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+    o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+    o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+    o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+    float ss = o.x * o.x;
+    ss = fmaf(o.y, o.y, ss);
+    ss = fmaf(o.z, o.z, ss);
+    ss = fmaf(o.w, o.w, ss);
+    ss = row16_sum(ss);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+    o.x *= inv;
+    o.y *= inv;
+    o.z *= inv;
+    o.w *= inv;
+    *reinterpret_cast<float4 *>(embed + (size_t)pix * 64 + 4 * t) = o;
+  }
+}
+
+int launch_head(const float *fa, const float *fb, float *embed, int B, int h, int w, int H, int W, hipStream_t st) {
+  const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+  const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  const long total = (long)B * H * W;
+  long blocks = (total / 4 + 3) / 4;  // 4 waves per block, 4 pixels per wave step
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fa, fb, embed, B, h, w, H, W, sy, sx);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+}  // namespace uoc

@@ -1,0 +1,340 @@
+// Two-branch RGB-D ResNet34-8s embedding network on gfx950: parameter intake (reference
+// state-dict names), BatchNorm folding, weight re-layout, and the forward pass as a fixed
+// sequence of hand-written kernels (csrc/conv.hip).
+//
+// Structure follows /root/reference/lib/networks:
+//   SEG.py:69-71,105-108,113-114   two Resnet34_8s (fcn on BGR image, fcn_depth on XYZ), add, L2-normalise
+//   resnet_dilated.py:287-327      resnet34(fully_conv, output_stride=8, no avgpool), fc=Conv2d(512,64,1)+bias,
+//                                  upsample_bilinear to the input size (align_corners=True)
+//   resnet.py:116-270              stem 7x7 s2 + BN + ReLU + maxpool; layers [3,4,6,3] of BasicBlocks;
+//                                  :188-234 stride->dilation once the stride reaches 8 (layer3 d=2, layer4 d=4)
+#include <map>
+#include <string>
+#include <vector>
+
+#include "conv.h"
+
+namespace uoc {
+
+struct ConvLayer {
+  std::string conv, bn;  // parameter prefixes relative to "<branch>.resnet34_8s."
+  int Cin, Cout, K, stride, dil, pad, relu;
+  bool has_bn, has_bias, stem;
+  float *d_w = nullptr, *d_b = nullptr;  // [G][...]
+  size_t w_per_group = 0;
+};
+
+struct Block {
+  int conv1, conv2, down;  // indices into layers, down = -1 if identity shortcut
+};
+
+}  // namespace uoc
+
+struct uoc_net {
+  std::map<std::string, std::vector<float>> params;
+  std::vector<uoc::ConvLayer> layers;
+  std::vector<uoc::Block> blocks;
+  int stem = -1, fc = -1;
+  bool finalized = false;
+  int device = -1;
+};
+
+namespace uoc {
+
+static const char *kBranch[2] = {"fcn", "fcn_depth"};
+constexpr int G = 2;
+
+static int add_conv(uoc_net *n, const std::string &conv, const std::string &bn, int Cin, int Cout, int K, int stride,
+                    int dil, int relu, bool has_bn, bool has_bias, bool stem = false) {
+  ConvLayer L;
+  L.conv = conv;
+  L.bn = bn;
+  L.Cin = Cin;
+  L.Cout = Cout;
+  L.K = K;
+  L.stride = stride;
+  L.dil = dil;
+  L.pad = stem ? 3 : (K == 3 ? dil : 0);
+  L.relu = relu;
+  L.has_bn = has_bn;
+  L.has_bias = has_bias;
+  L.stem = stem;
+  n->layers.push_back(L);
+  return (int)n->layers.size() - 1;
+}
+
+static void build_graph(uoc_net *n) {
+  n->stem = add_conv(n, "conv1", "bn1", 3, 64, 7, 2, 1, 1, true, false, true);
+  const int nblocks[4] = {3, 4, 6, 3};
+  const int planes[4] = {64, 128, 256, 512};
+  int inpl = 64, cur_stride = 4, cur_dil = 1;
+  for (int li = 0; li < 4; ++li) {
+    int stride = li == 0 ? 1 : 2;
+    const bool need_down = stride != 1 || inpl != planes[li];
+    if (need_down) {
+      if (cur_stride == 8) {  // output_stride reached: trade the stride for dilation (resnet.py:201-206)
+        cur_dil *= stride;
+        stride = 1;
+      } else {
+        cur_stride *= stride;
+      }
+    }
+    for (int bi = 0; bi < nblocks[li]; ++bi) {
+      const std::string pfx = "layer" + std::to_string(li + 1) + "." + std::to_string(bi) + ".";
+      Block b;
+      const int s = bi == 0 ? stride : 1;
+      const int cin = bi == 0 ? inpl : planes[li];
+      b.conv1 = add_conv(n, pfx + "conv1", pfx + "bn1", cin, planes[li], 3, s, cur_dil, 1, true, false);
+      b.conv2 = add_conv(n, pfx + "conv2", pfx + "bn2", planes[li], planes[li], 3, 1, cur_dil, 1, true, false);
+      b.down = -1;
+      if (bi == 0 && need_down)
+        b.down = add_conv(n, pfx + "downsample.0", pfx + "downsample.1", cin, planes[li], 1, s, 1, 0, true, false);
+      n->blocks.push_back(b);
+    }
+    inpl = planes[li];
+  }
+  n->fc = add_conv(n, "fc", "", 512, 64, 1, 1, 1, 0, false, true);
+}
+
+static const std::vector<float> *find(const uoc_net *n, const std::string &key, size_t numel) {
+  auto it = n->params.find(key);
+  if (it == n->params.end()) {
+    set_error("missing parameter '%s'", key.c_str());
+    return nullptr;
+  }
+  if (it->second.size() != numel) {
+    set_error("parameter '%s' has %zu elements, expected %zu", key.c_str(), it->second.size(), numel);
+    return nullptr;
+  }
+  return &it->second;
+}
+
+static int finalize_layer(uoc_net *n, ConvLayer &L) {
+  const int T = L.stem ? 7 : L.K * L.K;
+  const int Kc = L.stem ? 32 : L.Cin;
+  L.w_per_group = (size_t)T * L.Cout * Kc;
+  std::vector<float> hw((size_t)G * L.w_per_group, 0.f), hb((size_t)G * L.Cout, 0.f);
+  for (int g = 0; g < G; ++g) {
+    const std::string base = std::string(kBranch[g]) + ".resnet34_8s.";
+    const auto *w = find(n, base + L.conv + ".weight", (size_t)L.Cout * L.Cin * L.K * L.K);
+    if (!w) return UOC_ENOENT;
+    std::vector<double> scale(L.Cout, 1.0), shift(L.Cout, 0.0);
+    if (L.has_bn) {
+      const auto *ga = find(n, base + L.bn + ".weight", L.Cout);
+      const auto *be = find(n, base + L.bn + ".bias", L.Cout);
+      const auto *mu = find(n, base + L.bn + ".running_mean", L.Cout);
+      const auto *va = find(n, base + L.bn + ".running_var", L.Cout);
+      if (!ga || !be || !mu || !va) return UOC_ENOENT;
+      for (int c = 0; c < L.Cout; ++c) {
+        const double inv = 1.0 / sqrt((double)(*va)[c] + 1e-5);  // BatchNorm2d eps (resnet.py:143)
+        scale[c] = (double)(*ga)[c] * inv;
+        shift[c] = (double)(*be)[c] - (double)(*mu)[c] * scale[c];
+      }
+    }
+    if (L.has_bias) {
+      const auto *bi = find(n, base + L.conv + ".bias", L.Cout);
+      if (!bi) return UOC_ENOENT;
+      for (int c = 0; c < L.Cout; ++c) shift[c] += (double)(*bi)[c];
+    }
+    float *dst = hw.data() + (size_t)g * L.w_per_group;
+    for (int co = 0; co < L.Cout; ++co)
+      for (int ci = 0; ci < L.Cin; ++ci)
+        for (int kh = 0; kh < L.K; ++kh)
+          for (int kw = 0; kw < L.K; ++kw) {
+            const double v = (double)(*w)[(((size_t)co * L.Cin + ci) * L.K + kh) * L.K + kw] * scale[co];
+            size_t o;
+            if (L.stem)  // [kh][cout][kw(8)][ch(4)]
+              o = ((size_t)kh * L.Cout + co) * 32 + kw * 4 + ci;
+            else  // [tap][cout][cin]
+              o = ((size_t)(kh * L.K + kw) * L.Cout + co) * L.Cin + ci;
+            dst[o] = (float)v;
+          }
+    for (int c = 0; c < L.Cout; ++c) hb[(size_t)g * L.Cout + c] = (float)shift[c];
+  }
+  UOC_HIP_CHECK(hipMalloc(&L.d_w, hw.size() * sizeof(float)));
+  UOC_HIP_CHECK(hipMalloc(&L.d_b, hb.size() * sizeof(float)));
+  UOC_HIP_CHECK(hipMemcpy(L.d_w, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice));
+  UOC_HIP_CHECK(hipMemcpy(L.d_b, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+  return UOC_OK;
+}
+
+struct Dims {
+  int H1, W1, H2, W2, H3, W3;
+};
+static Dims dims(int H, int W) {
+  Dims d;
+  d.H1 = (H - 1) / 2 + 1;  // conv 7x7 s2 p3
+  d.W1 = (W - 1) / 2 + 1;
+  d.H2 = (d.H1 - 1) / 2 + 1;  // maxpool 3x3 s2 p1
+  d.W2 = (d.W1 - 1) / 2 + 1;
+  d.H3 = (d.H2 - 1) / 2 + 1;  // layer2 stride 2
+  d.W3 = (d.W2 - 1) / 2 + 1;
+  return d;
+}
+
+struct NetWs {
+  float *in4, *stem, *buf[4], *fc;
+  size_t total;
+};
+static NetWs carve_net(void *base, int B, int H, int W) {
+  const Dims d = dims(H, W);
+  NetWs w;
+  size_t off = 0;
+  auto take = [&](size_t floats) {
+    float *p = base ? (float *)((char *)base + off) : nullptr;
+    off += align_up(floats * sizeof(float), 256);
+    return p;
+  };
+  w.in4 = take((size_t)G * B * H * W * 4);
+  w.stem = take((size_t)G * B * d.H1 * d.W1 * 64);
+  size_t act = (size_t)G * B * d.H2 * d.W2 * 64;
+  const size_t a3 = (size_t)G * B * d.H3 * d.W3 * 512;
+  if (a3 > act) act = a3;
+  for (int i = 0; i < 4; ++i) w.buf[i] = take(act);
+  w.fc = take((size_t)G * B * d.H3 * d.W3 * 64);
+  w.total = off;
+  return w;
+}
+
+static int run_conv(const ConvLayer &L, const float *in, const float *res, float *out, int B, int H, int W, int Ho,
+                    int Wo, hipStream_t st) {
+  ConvParams p;
+  p.in = in;
+  p.w = L.d_w;
+  p.bias = L.d_b;
+  p.res = res;
+  p.out = out;
+  p.G = G;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.Cin = L.stem ? 4 : L.Cin;
+  p.Ho = Ho;
+  p.Wo = Wo;
+  p.Cout = L.Cout;
+  p.KH = p.KW = L.K;
+  p.stride = L.stride;
+  p.dil = L.dil;
+  p.pad = L.pad;
+  p.relu = L.relu;
+  p.stem = L.stem ? 1 : 0;
+  return launch_conv(p, st);
+}
+
+}  // namespace uoc
+
+using namespace uoc;
+
+extern "C" {
+
+int uoc_net_create(uoc_net **out) {
+  UOC_REQUIRE(out != nullptr, "out is null");
+  uoc_net *n = new (std::nothrow) uoc_net();
+  if (!n) {
+    set_error("out of host memory");
+    return UOC_ENOMEM;
+  }
+  build_graph(n);
+  *out = n;
+  return UOC_OK;
+}
+
+int uoc_net_destroy(uoc_net *n) {
+  if (!n) return UOC_OK;
+  for (auto &L : n->layers) {
+    if (L.d_w) (void)hipFree(L.d_w);
+    if (L.d_b) (void)hipFree(L.d_b);
+  }
+  delete n;
+  return UOC_OK;
+}
+
+int uoc_net_load_param(uoc_net *n, const char *name, const float *host, size_t numel) {
+  UOC_REQUIRE(n && name && host, "null argument");
+  UOC_REQUIRE(!n->finalized, "network already finalized");
+  n->params[std::string(name)] = std::vector<float>(host, host + numel);
+  return UOC_OK;
+}
+
+int uoc_net_finalize(uoc_net *n) {
+  UOC_REQUIRE(n != nullptr, "net is null");
+  UOC_REQUIRE(!n->finalized, "network already finalized");
+  UOC_HIP_CHECK(hipGetDevice(&n->device));
+  for (auto &L : n->layers)
+    if (int rc = finalize_layer(n, L)) return rc;
+  n->params.clear();
+  n->finalized = true;
+  return UOC_OK;
+}
+
+size_t uoc_net_workspace_bytes(const uoc_net *n, int B, int H, int W) {
+  (void)n;
+  if (B < 1 || H < 8 || W < 8) return 0;
+  return carve_net(nullptr, B, H, W).total;
+}
+
+int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, int H, int W, float *d_embed,
+                    void *d_ws, size_t ws_bytes, void *stream) {
+  UOC_REQUIRE(n && n->finalized, "network not finalized");
+  UOC_REQUIRE(d_rgb && d_xyz && d_embed, "null tensor pointer");
+  UOC_REQUIRE(B >= 1 && H >= 8 && W >= 8, "bad input shape B=%d H=%d W=%d", B, H, W);
+  const NetWs w = carve_net(d_ws, B, H, W);
+  UOC_REQUIRE(d_ws && ws_bytes >= w.total && ((uintptr_t)d_ws & 255) == 0, "workspace too small or misaligned (%zu < %zu)",
+              ws_bytes, w.total);
+  hipStream_t st = (hipStream_t)stream;
+  const Dims d = dims(H, W);
+
+  // inputs -> NHWC4, group 0 = BGR image, group 1 = XYZ
+  if (int rc = launch_nchw3_to_nhwc4(d_rgb, w.in4, B, H, W, st)) return rc;
+  if (int rc = launch_nchw3_to_nhwc4(d_xyz, w.in4 + (size_t)B * H * W * 4, B, H, W, st)) return rc;
+  if (int rc = run_conv(n->layers[n->stem], w.in4, nullptr, w.stem, B, H, W, d.H1, d.W1, st)) return rc;
+  if (int rc = launch_maxpool3x3s2(w.stem, w.buf[0], G * B, d.H1, d.W1, 64, d.H2, d.W2, st)) return rc;
+
+  int cur = 0, h = d.H2, wd = d.W2;
+  for (const Block &b : n->blocks) {
+    const ConvLayer &c1 = n->layers[b.conv1], &c2 = n->layers[b.conv2];
+    const int ho = (h - 1) / c1.stride + 1, wo = (wd - 1) / c1.stride + 1;
+    float *x = w.buf[cur], *tmp = w.buf[(cur + 1) & 3], *sc = w.buf[(cur + 2) & 3], *y = w.buf[(cur + 3) & 3];
+    if (int rc = run_conv(c1, x, nullptr, tmp, B, h, wd, ho, wo, st)) return rc;
+    const float *res = x;
+    if (b.down >= 0) {
+      if (int rc = run_conv(n->layers[b.down], x, nullptr, sc, B, h, wd, ho, wo, st)) return rc;
+      res = sc;
+    }
+    if (int rc = run_conv(c2, tmp, res, y, B, ho, wo, ho, wo, st)) return rc;
+    cur = (cur + 3) & 3;
+    h = ho;
+    wd = wo;
+  }
+  if (int rc = run_conv(n->layers[n->fc], w.buf[cur], nullptr, w.fc, B, h, wd, h, wd, st)) return rc;
+  return launch_head(w.fc, w.fc + (size_t)B * h * wd * 64, d_embed, B, h, wd, H, W, st);
+}
+
+/* Generic NHWC convolution entry (unit tests / integration): weights [T][Cout][Cin] with BN folded. */
+int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, const float *d_res, float *d_out, int B,
+                    int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu, void *stream) {
+  UOC_REQUIRE(K == 1 || K == 3, "K=%d (only 1 or 3)", K);
+  ConvParams p;
+  p.in = d_in;
+  p.w = d_w;
+  p.bias = d_bias;
+  p.res = d_res;
+  p.out = d_out;
+  p.G = 1;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.Cin = Cin;
+  p.Cout = Cout;
+  p.KH = p.KW = K;
+  p.stride = stride;
+  p.dil = dil;
+  p.pad = pad;
+  p.relu = relu;
+  p.stem = 0;
+  p.Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  p.Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  return launch_conv(p, (hipStream_t)stream);
+}
+
+}  // extern "C"
