@@ -99,6 +99,46 @@ int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, co
                     int B, int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu,
                     void *stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Two-stage glue — replaces lib/fcn/test_dataset.py:62-198 (filter_labels_depth, crop_rois,
+ * match_label_crop) with batched device kernels.  Label maps are int32 with ids < 128.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct uoc_roi_table {
+  int32_t K;            /* number of ROIs = non-zero labels present, ascending label order    */
+  int32_t label[128];   /* stage-1 label id of ROI k                                          */
+  int32_t box[128][4];  /* x0, y0, x1, y1 inclusive, padded 25 % and clamped (:83-93)         */
+} uoc_roi_table;
+
+size_t uoc_roi_workspace_bytes(void);
+
+/* filter_labels_depth (:183-198): per batch item, a non-zero label whose fraction of pixels with
+ * z > 0 is < threshold becomes 0.  d_z: the Z plane of item 0; items are z_batch_stride floats apart. */
+int uoc_filter_labels_depth(int32_t *d_labels, const float *d_z, long z_batch_stride, int B, int H, int W,
+                            float threshold, void *d_ws, size_t ws_bytes, void *stream);
+
+/* One pass that (optionally, d_z != NULL) applies the depth filter in place and builds the ROI
+ * table of crop_rois (:68-93; mask.py:180-187 tight box, round-half-even padding, clamping). */
+int uoc_roi_build(int32_t *d_labels, const float *d_z, int H, int W, float threshold, float pad_fraction,
+                  uoc_roi_table *d_table, void *d_ws, size_t ws_bytes, void *stream);
+
+/* crop_rois (:95-110): crops of the [3][H][W] image / XYZ planes resized to SxS with bilinear
+ * align_corners=True, object mask with nearest.  Outputs NCHW [K][3][S][S] and [K][S][S]. */
+int uoc_roi_crop(const float *d_rgb, const float *d_xyz, const int32_t *d_labels, int H, int W,
+                 const uoc_roi_table *d_table, int K, int S, float *d_rgb_crops, float *d_xyz_crops,
+                 float *d_mask_crops, void *stream);
+
+/* match_label_crop part 1 (:118-136): d_keep[k][c] = 1 iff crop cluster c of ROI k overlaps the
+ * stage-1 mask by >= 50 %; d_meanz[k] = mean z (>0) over kept pixels (all pixels if none kept). */
+int uoc_roi_match_stats(const int32_t *d_labels_crop, const float *d_mask_crops, const float *d_xyz_crops, int K,
+                        int S, int32_t *d_keep, float *d_meanz, void *d_ws, size_t ws_bytes, void *stream);
+
+/* match_label_crop part 2 (:156-177): d_map[k][c] = global id of kept cluster c (0 = dropped),
+ * d_order = ROI paint order (far to near); nearest-resize each crop back to its box and paste
+ * non-zeros, later ROIs overwrite earlier ones.  d_refined [H*W] is fully written. */
+int uoc_roi_paste(const int32_t *d_labels_crop, const uoc_roi_table *d_table, const int32_t *d_map,
+                  const int32_t *d_order, int K, int S, int H, int W, int32_t *d_refined, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

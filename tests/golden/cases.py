@@ -16,3 +16,75 @@ MEANSHIFT_CASES = {
 KAPPA = 20.0
 EPSILON = 0.04
 RNG_SEED = 3
+
+
+# ---------------------------------------------------------------------------------------------
+# Shared input builders (used by make_golden.py in the build container AND by the tests).
+# ---------------------------------------------------------------------------------------------
+import numpy as np
+import torch
+
+from unseenobjectclustering_amd import synth
+
+
+def sample_positions(seed, n, count):
+    return np.sort(np.random.default_rng(seed).choice(n, size=min(count, n), replace=False)).astype(np.int64)
+
+
+BACKBONE_CASES = {
+    # name -> (weight seed, frame seeds, H, W, num sampled pixels (0 = keep everything))
+    "tiny_64x64":   dict(wseed=1, frames=[7], H=64, W=64, samples=0),
+    "odd_72x104":   dict(wseed=2, frames=[8], H=72, W=104, samples=1024),
+    "crops_224":    dict(wseed=2, frames=[4, 5], H=224, W=224, samples=1024),
+    "full_480x640": dict(wseed=1, frames=[1], H=480, W=640, samples=2048),
+}
+
+
+GLUE_CASES = {
+    # name -> (frame seed, H, W, objects, tweak)
+    "normal_5":     dict(seed=31, H=480, W=640, objects=5, tweak=None),
+    "border_8":     dict(seed=32, H=480, W=640, objects=8, tweak="border"),
+    "zero_depth":   dict(seed=33, H=480, W=640, objects=4, tweak="zero_depth"),
+    "no_objects":   dict(seed=34, H=240, W=320, objects=0, tweak="empty"),
+    "small_ragged": dict(seed=35, H=123, W=157, objects=3, tweak=None),
+}
+
+
+def glue_inputs(c):
+    """Label map (float, label 0 = background+table as after the largest-cluster swap), image, xyz."""
+    fr = synth.rgbd_frame(c["seed"], c["H"], c["W"], c["objects"])
+    lab = fr["label"].copy()
+    lab = np.where(lab <= 1, 0, lab - 1).astype(np.float32)      # objects 1..K
+    depth = fr["depth"].copy()
+    if c["tweak"] == "border":
+        lab[:40, :60] = lab.max() + 1                               # object touching the image corner
+        lab[-1, :] = lab.max() + 1                                  # one-pixel-high object on the last row
+    if c["tweak"] == "zero_depth" and lab.max() >= 2:
+        depth[0, 2][lab == 2] = 0.0                                 # object 2 has no valid depth -> filtered
+        half = (lab == 1) & (np.arange(lab.shape[1])[None, :] % 4 != 0)
+        depth[0, 2][half] = 0.0                                     # object 1: 25 % coverage -> filtered
+    if c["tweak"] == "empty":
+        lab[:] = 0
+    return torch.from_numpy(fr["image_color"]), torch.from_numpy(lab)[None], torch.from_numpy(depth), fr["label"]
+
+
+def crop_cluster_labels(c, gt, rois):
+    """Synthetic stage-2 cluster maps: nearest crop of the generating label map, object split in two."""
+    out = []
+    for k in range(rois.shape[0]):
+        x0, y0, x1, y1 = [int(v) for v in rois[k]]
+        g = torch.from_numpy(gt[y0:y1 + 1, x0:x1 + 1].astype(np.float32))
+        g = torch.nn.functional.interpolate(g[None, None], size=(224, 224), mode="nearest")[0, 0]
+        g[:, 112:][g[:, 112:] == g.max()] += 3                      # split the top label into two clusters
+        out.append(g)
+    return torch.stack(out) if out else torch.zeros((0, 224, 224))
+
+
+E2E_CASES = {"e2e_a": dict(seed=41, objects=5), "e2e_b": dict(seed=42, objects=3)}
+
+
+def e2e_stub_features(seed, H, W, objects):
+    X, _ = synth.embedding_field(seed, H, W, 64, objects, 0.05)
+    return torch.from_numpy(X).view(H, W, 64).permute(2, 0, 1)[None].contiguous()
+
+

@@ -20,7 +20,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 import ref_harness  # noqa: E402
-from cases import MEANSHIFT_CASES, KAPPA, EPSILON, RNG_SEED  # noqa: E402
+from cases import (MEANSHIFT_CASES, KAPPA, EPSILON, RNG_SEED, BACKBONE_CASES, GLUE_CASES, E2E_CASES,  # noqa: E402
+                   sample_positions, glue_inputs, crop_cluster_labels, e2e_stub_features)
 from unseenobjectclustering_amd import synth  # noqa: E402
 
 
@@ -49,19 +50,6 @@ def make_meanshift(ref):
     np.savez_compressed(os.path.join(HERE, "meanshift.npz"), **out)
 
 
-def sample_positions(seed, n, count):
-    return np.sort(np.random.default_rng(seed).choice(n, size=min(count, n), replace=False)).astype(np.int64)
-
-
-BACKBONE_CASES = {
-    # name -> (weight seed, frame seeds, H, W, num sampled pixels (0 = keep everything))
-    "tiny_64x64":   dict(wseed=1, frames=[7], H=64, W=64, samples=0),
-    "odd_72x104":   dict(wseed=2, frames=[8], H=72, W=104, samples=0),
-    "crops_224":    dict(wseed=2, frames=[4, 5], H=224, W=224, samples=1024),
-    "full_480x640": dict(wseed=1, frames=[1], H=480, W=640, samples=2048),
-}
-
-
 def make_backbone(ref):
     import contextlib
     import io
@@ -87,6 +75,48 @@ def make_backbone(ref):
     np.savez_compressed(os.path.join(HERE, "backbone.npz"), **out)
 
 
+def make_glue(ref):
+    td = ref.test_dataset
+    out = {}
+    for name, c in GLUE_CASES.items():
+        img, lab, depth, gt = glue_inputs(c)
+        filt = td.filter_labels_depth(lab, depth, 0.8)
+        out[name + "/filtered"] = filt.numpy().astype(np.uint8)
+        rgb_c, mask_c, rois, depth_c = td.crop_rois(img, filt.clone(), depth)
+        K = rgb_c.shape[0]
+        out[name + "/rois"] = rois.numpy().astype(np.int32)
+        out[name + "/mask_crops"] = np.packbits(mask_c.numpy().astype(np.uint8), axis=None)
+        pos = sample_positions(5, 3 * 224 * 224, 768)
+        out[name + "/crop_pos"] = pos
+        out[name + "/rgb_crops_s"] = rgb_c.reshape(K, -1)[:, pos].numpy() if K else np.zeros((0, 768), np.float32)
+        out[name + "/depth_crops_s"] = depth_c.reshape(K, -1)[:, pos].numpy() if K else np.zeros((0, 768), np.float32)
+        out[name + "/rgb_crops_sum"] = rgb_c.double().sum(dim=(1, 2, 3)).numpy()
+        if K:
+            labels_c = crop_cluster_labels(c, gt, rois)
+            refined, labels_c2 = td.match_label_crop(filt, labels_c.clone(), mask_c, rois, depth_c)
+            out[name + "/refined"] = refined.numpy().astype(np.uint8)
+            out[name + "/labels_crop_out"] = labels_c2.numpy().astype(np.int8)
+        print(name, "K =", K, "rois", rois.numpy().astype(int).tolist(), flush=True)
+    np.savez_compressed(os.path.join(HERE, "glue.npz"), **out)
+
+
+def make_e2e(ref):
+    td = ref.test_dataset
+    out = {}
+    for name, c in E2E_CASES.items():
+        fr = synth.rgbd_frame(c["seed"], 480, 640, c["objects"])
+        sample = dict(image_color=torch.from_numpy(fr["image_color"]), depth=torch.from_numpy(fr["depth"]))
+        net = lambda img, label, depth, c=c: e2e_stub_features(c["seed"], 480, 640, c["objects"] + 2)
+        net_crop = lambda rgb, label, depth, c=c: torch.cat(
+            [e2e_stub_features(1000 + 10 * c["seed"] + k, 224, 224, 2 + k % 3) for k in range(rgb.shape[0])])
+        np.random.seed(RNG_SEED)
+        out_label, refined = td.test_sample(sample, net, net_crop)
+        out[name + "/out_label"] = out_label.numpy().astype(np.uint8)
+        out[name + "/refined"] = refined.numpy().astype(np.uint8)
+        print(name, "labels", np.unique(out[name + "/out_label"]).tolist(), "refined", np.unique(out[name + "/refined"]).tolist(), flush=True)
+    np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
+
+
 def main():
     assert ref_harness.available(), "reference tree not present: golden vectors can only be made in the build container"
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -96,6 +126,10 @@ def main():
         make_meanshift(ref)
     if what in ("backbone", "all"):
         make_backbone(ref)
+    if what in ("glue", "all"):
+        make_glue(ref)
+    if what in ("e2e", "all"):
+        make_e2e(ref)
 
 
 if __name__ == "__main__":

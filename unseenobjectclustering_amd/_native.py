@@ -37,6 +37,15 @@ def _declare(lib):
     for name in ("uoc_net_create", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_forward",
                  "uoc_conv2d_nhwc"):
         getattr(lib, name).restype = c_int
+    lib.uoc_roi_workspace_bytes.restype = c_size_t
+    lib.uoc_roi_workspace_bytes.argtypes = []
+    lib.uoc_filter_labels_depth.argtypes = [P, P, ctypes.c_long, c_int, c_int, c_int, c_float, P, c_size_t, P]
+    lib.uoc_roi_build.argtypes = [P, P, c_int, c_int, c_float, c_float, P, P, c_size_t, P]
+    lib.uoc_roi_crop.argtypes = [P, P, P, c_int, c_int, P, c_int, c_int, P, P, P, P]
+    lib.uoc_roi_match_stats.argtypes = [P, P, P, c_int, c_int, P, P, P, c_size_t, P]
+    lib.uoc_roi_paste.argtypes = [P, P, P, P, c_int, c_int, c_int, c_int, P, P]
+    for name in ("uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats", "uoc_roi_paste"):
+        getattr(lib, name).restype = c_int
     for name in ("uoc_ms_select_seeds", "uoc_ms_hill_climb", "uoc_ms_seed_components", "uoc_ms_assign",
                  "uoc_ms_cluster"):
         getattr(lib, name).restype = c_int
@@ -48,7 +57,17 @@ EXPORTED_SYMBOLS = (
     "uoc_ms_seed_components", "uoc_ms_assign", "uoc_ms_cluster",
     "uoc_net_create", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",
     "uoc_net_forward", "uoc_conv2d_nhwc",
+    "uoc_roi_workspace_bytes", "uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats",
+    "uoc_roi_paste",
 )
+
+
+class RoiTable(ctypes.Structure):
+    """Mirror of uoc_roi_table (include/uoc_hip.h)."""
+    _fields_ = [("K", c_int32), ("label", c_int32 * 128), ("box", (c_int32 * 4) * 128)]
+
+
+ROI_TABLE_BYTES = ctypes.sizeof(RoiTable)
 
 
 def lib():

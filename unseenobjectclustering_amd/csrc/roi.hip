@@ -1,0 +1,354 @@
+// Two-stage glue on the device: depth-coverage filter, per-object ROI boxes, crop+resize to
+// 224x224, crop-cluster matching statistics and paste-back — batched over ROIs, no per-object
+// host round trips.
+//
+// Replaces /root/reference/lib/fcn/test_dataset.py:
+//   filter_labels_depth :183-198   -> label_stats_kernel + roi_build_kernel + apply_lut_kernel
+//   crop_rois           :62-112    -> (same stats pass) + roi_crop_kernel   (mask.py:180-187 tight box)
+//   match_label_crop    :116-179   -> crop_stats_kernel + crop_meanz_kernel (+ host ordering) + paste_kernel
+//
+// Interpolation index arithmetic follows ATen's float formulas so that crops are the ones the
+// reference's F.upsample_bilinear (align_corners=True) / F.upsample_nearest produce:
+//   bilinear: src = dst * (in-1)/(out-1), i0 = (int)src, lambda = src - i0
+//   nearest : src = min((int)floorf(dst * (float)in/out), in-1)
+#include "common.h"
+
+#include <limits.h>
+#include <math.h>
+
+namespace uoc {
+
+constexpr int NL = UOC_MAX_SEEDS;  // label ids are < 128
+
+// stats layout per label: [cnt, zpos, maxx+1, W-minx, maxy+1, H-miny]  (all "max" accumulators, zero = empty)
+constexpr int NSTAT = 6;
+
+__global__ __launch_bounds__(256) void label_stats_kernel(const int *__restrict__ labels, const float *__restrict__ z,
+                                                          int H, int W, int *__restrict__ stats) {
+  __shared__ int s[NL * NSTAT];
+  for (int i = threadIdx.x; i < NL * NSTAT; i += blockDim.x) s[i] = 0;
+  __syncthreads();
+  const int n = H * W;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const int l = labels[p];
+    if ((unsigned)l >= (unsigned)NL) continue;
+    const int y = p / W, x = p - y * W;
+    atomicAdd(&s[l * NSTAT + 0], 1);
+    if (z && z[p] > 0.f) atomicAdd(&s[l * NSTAT + 1], 1);
+    atomicMax(&s[l * NSTAT + 2], x + 1);
+    atomicMax(&s[l * NSTAT + 3], W - x);
+    atomicMax(&s[l * NSTAT + 4], y + 1);
+    atomicMax(&s[l * NSTAT + 5], H - y);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NL * NSTAT; i += blockDim.x) {
+    const int v = s[i];
+    if (v == 0) continue;
+    if (i % NSTAT < 2)
+      atomicAdd(&stats[i], v);
+    else
+      atomicMax(&stats[i], v);
+  }
+}
+
+// One block of 128 threads: thread l owns label l.
+__global__ __launch_bounds__(NL) void roi_build_kernel(const int *__restrict__ stats, int use_filter, float thr,
+                                                       float pad_frac, int H, int W, int *__restrict__ lut,
+                                                       uoc_roi_table *__restrict__ table) {
+  __shared__ int alive[NL];
+  const int l = threadIdx.x;
+  const int cnt = stats[l * NSTAT + 0], zpos = stats[l * NSTAT + 1];
+  bool present = cnt > 0;
+  bool filtered = false;
+  if (use_filter && present && l != 0) {
+    // torch.sum(roi_depth > 0).float() / torch.sum(mask)  <  threshold   (test_dataset.py:194-196)
+    filtered = ((float)zpos / (float)cnt) < thr;
+  }
+  lut[l] = filtered ? 0 : l;
+  alive[l] = (present && !filtered && l != 0) ? 1 : 0;
+  __syncthreads();
+  if (!table) return;
+  int rank = 0;
+  for (int i = 0; i < l; ++i) rank += alive[i];
+  if (alive[l]) {
+    const int x1 = stats[l * NSTAT + 2] - 1, x0 = W - stats[l * NSTAT + 3];
+    const int y1 = stats[l * NSTAT + 4] - 1, y0 = H - stats[l * NSTAT + 5];
+    // int(torch.round((x_max - x_min).float() * 0.25))  — round half to even (:83-84)
+    const int px = (int)rintf((float)(x1 - x0) * pad_frac);
+    const int py = (int)rintf((float)(y1 - y0) * pad_frac);
+    table->label[rank] = l;
+    table->box[rank][0] = max(x0 - px, 0);
+    table->box[rank][1] = max(y0 - py, 0);
+    table->box[rank][2] = min(x1 + px, W - 1);
+    table->box[rank][3] = min(y1 + py, H - 1);
+  }
+  if (l == NL - 1) table->K = rank + alive[l];
+}
+
+__global__ __launch_bounds__(256) void apply_lut_kernel(int *__restrict__ labels, int n, const int *__restrict__ lut) {
+  __shared__ int s[NL];
+  if (threadIdx.x < NL) s[threadIdx.x] = lut[threadIdx.x];
+  __syncthreads();
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const int l = labels[p];
+    if ((unsigned)l < (unsigned)NL) labels[p] = s[l];
+  }
+}
+
+// grid (ceil(S*S/256), K).  rgb/xyz: [3][H][W] planes; outputs NCHW crops [K][3][S][S], mask [K][S][S].
+__global__ __launch_bounds__(256) void roi_crop_kernel(const float *__restrict__ rgb, const float *__restrict__ xyz,
+                                                       const int *__restrict__ labels, int H, int W,
+                                                       const uoc_roi_table *__restrict__ table, int S,
+                                                       float *__restrict__ out_rgb, float *__restrict__ out_xyz,
+                                                       float *__restrict__ out_mask) {
+  const int k = blockIdx.y;
+  const int x0 = table->box[k][0], y0 = table->box[k][1], x1 = table->box[k][2], y1 = table->box[k][3];
+  const int lab = table->label[k];
+  const int cw = x1 - x0 + 1, ch = y1 - y0 + 1;
+  const float sy = S > 1 ? (float)(ch - 1) / (float)(S - 1) : 0.f;
+  const float sx = S > 1 ? (float)(cw - 1) / (float)(S - 1) : 0.f;
+  const float ny = (float)ch / (float)S, nx = (float)cw / (float)S;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= S * S) return;
+  const int oy = i / S, ox = i - oy * S;
+  // bilinear, align_corners=True (:104,109)
+  const float fy = sy * (float)oy, fx = sx * (float)ox;
+  int iy0 = (int)fy, ix0 = (int)fx;
+  if (iy0 > ch - 1) iy0 = ch - 1;
+  if (ix0 > cw - 1) ix0 = cw - 1;
+  const int iy1 = iy0 + (iy0 < ch - 1 ? 1 : 0), ix1 = ix0 + (ix0 < cw - 1 ? 1 : 0);
+  const float ly = fminf(fmaxf(fy - (float)iy0, 0.f), 1.f), lx = fminf(fmaxf(fx - (float)ix0, 0.f), 1.f);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const size_t o00 = (size_t)(y0 + iy0) * W + (x0 + ix0), o01 = (size_t)(y0 + iy0) * W + (x0 + ix1);
+  const size_t o10 = (size_t)(y0 + iy1) * W + (x0 + ix0), o11 = (size_t)(y0 + iy1) * W + (x0 + ix1);
+  const size_t HW = (size_t)H * W, SS = (size_t)S * S;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float *a = rgb + c * HW;
+    out_rgb[((size_t)k * 3 + c) * SS + i] = (a[o00] * hx + a[o01] * lx) * hy + (a[o10] * hx + a[o11] * lx) * ly;
+    const float *d = xyz + c * HW;
+    out_xyz[((size_t)k * 3 + c) * SS + i] = (d[o00] * hx + d[o01] * lx) * hy + (d[o10] * hx + d[o11] * lx) * ly;
+  }
+  // nearest (:106)
+  int my = (int)floorf((float)oy * ny), mx = (int)floorf((float)ox * nx);
+  if (my > ch - 1) my = ch - 1;
+  if (mx > cw - 1) mx = cw - 1;
+  out_mask[(size_t)k * SS + i] = labels[(size_t)(y0 + my) * W + (x0 + mx)] == lab ? 1.f : 0.f;
+}
+
+// per ROI / per crop-cluster id: pixel count and overlap with the stage-1 mask (:118-125)
+__global__ __launch_bounds__(256) void crop_stats_kernel(const int *__restrict__ labels_crop,
+                                                         const float *__restrict__ mask_crop, int SS,
+                                                         int *__restrict__ cnt, int *__restrict__ ov) {
+  __shared__ int sc[NL], so[NL];
+  const int k = blockIdx.y;
+  if (threadIdx.x < NL) {
+    sc[threadIdx.x] = 0;
+    so[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < SS; i += gridDim.x * blockDim.x) {
+    const int l = labels_crop[(size_t)k * SS + i];
+    if ((unsigned)l >= (unsigned)NL) continue;
+    atomicAdd(&sc[l], 1);
+    if (mask_crop[(size_t)k * SS + i] != 0.f) atomicAdd(&so[l], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < NL) {
+    if (sc[threadIdx.x]) atomicAdd(&cnt[k * NL + threadIdx.x], sc[threadIdx.x]);
+    if (so[threadIdx.x]) atomicAdd(&ov[k * NL + threadIdx.x], so[threadIdx.x]);
+  }
+}
+
+// keep[k][c] = cluster c of ROI k overlaps its stage-1 mask by >= 50 %; mean z of kept pixels
+// with z > 0 (all pixels if nothing is kept) (:129-136).  One block per ROI.
+__global__ __launch_bounds__(256) void crop_meanz_kernel(const int *__restrict__ labels_crop,
+                                                         const float *__restrict__ xyz_crop, int SS,
+                                                         const int *__restrict__ cnt, const int *__restrict__ ov,
+                                                         int *__restrict__ keep, float *__restrict__ meanz) {
+  __shared__ int sk[NL];
+  __shared__ int s_any;
+  __shared__ double rs[256];
+  __shared__ int rc[256];
+  const int k = blockIdx.x;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  if (threadIdx.x < NL) {
+    const int c = cnt[k * NL + threadIdx.x], o = ov[k * NL + threadIdx.x];
+    const int kp = (c > 0 && !(((float)o / (float)c) < 0.5f)) ? 1 : 0;
+    sk[threadIdx.x] = kp;
+    keep[k * NL + threadIdx.x] = kp;
+    if (kp) atomicOr(&s_any, 1);
+  }
+  __syncthreads();
+  const int any = s_any;
+  const float *z = xyz_crop + ((size_t)k * 3 + 2) * SS;
+  double sum = 0.0;
+  int n = 0;
+  for (int i = threadIdx.x; i < SS; i += blockDim.x) {
+    const int l = labels_crop[(size_t)k * SS + i];
+    const bool sel = any ? ((unsigned)l < (unsigned)NL && sk[l]) : true;
+    const float v = z[i];
+    if (sel && v > 0.f) {
+      sum += (double)v;
+      ++n;
+    }
+  }
+  rs[threadIdx.x] = sum;
+  rc[threadIdx.x] = n;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if (threadIdx.x < off) {
+      rs[threadIdx.x] += rs[threadIdx.x + off];
+      rc[threadIdx.x] += rc[threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) meanz[k] = (float)(rs[0] / (double)rc[0]);  // 0/0 -> NaN like torch.mean of an empty tensor
+}
+
+// refined[p] = relabelled crop cluster of the LAST ROI (in paint order) covering p with a kept
+// cluster; 0 otherwise (:165-177; nearest resize back to the ROI size).
+__global__ __launch_bounds__(256) void paste_kernel(const int *__restrict__ labels_crop,
+                                                    const uoc_roi_table *__restrict__ table,
+                                                    const int *__restrict__ map, const int *__restrict__ order, int K,
+                                                    int S, int H, int W, int *__restrict__ refined) {
+  const int n = H * W, SS = S * S;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const int y = p / W, x = p - y * W;
+    int val = 0;
+    for (int j = K - 1; j >= 0; --j) {
+      const int k = order[j];
+      const int x0 = table->box[k][0], y0 = table->box[k][1], x1 = table->box[k][2], y1 = table->box[k][3];
+      if (x < x0 || x > x1 || y < y0 || y > y1) continue;
+      const int w = x1 - x0 + 1, h = y1 - y0 + 1;
+      int sy = (int)floorf((float)(y - y0) * ((float)S / (float)h));
+      int sx = (int)floorf((float)(x - x0) * ((float)S / (float)w));
+      if (sy > S - 1) sy = S - 1;
+      if (sx > S - 1) sx = S - 1;
+      const int l = labels_crop[(size_t)k * SS + sy * S + sx];
+      const int v = ((unsigned)l < (unsigned)NL) ? map[k * NL + l] : 0;
+      if (v != 0) {
+        val = v;
+        break;
+      }
+    }
+    refined[p] = val;
+  }
+}
+
+struct RoiWs {
+  int *stats;  // [128][6]
+  int *lut;    // [128]
+  int *cnt;    // [127][128]
+  int *ov;     // [127][128]
+  size_t total;
+};
+static RoiWs carve_roi(void *base) {
+  RoiWs w;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    void *p = base ? (void *)((char *)base + off) : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  w.stats = (int *)take(NL * NSTAT * sizeof(int));
+  w.lut = (int *)take(NL * sizeof(int));
+  w.cnt = (int *)take((size_t)NL * NL * sizeof(int));
+  w.ov = (int *)take((size_t)NL * NL * sizeof(int));
+  w.total = off;
+  return w;
+}
+
+static int grid_for(int n) {
+  int b = (n + 255) / 256;
+  if (b > 1024) b = 1024;
+  return b < 1 ? 1 : b;
+}
+
+}  // namespace uoc
+
+using namespace uoc;
+
+extern "C" {
+
+size_t uoc_roi_workspace_bytes(void) { return carve_roi(nullptr).total; }
+
+int uoc_filter_labels_depth(int32_t *d_labels, const float *d_z, long z_batch_stride, int B, int H, int W,
+                            float threshold, void *d_ws, size_t ws_bytes, void *stream) {
+  UOC_REQUIRE(d_labels && d_z && d_ws, "null pointer");
+  UOC_REQUIRE(B >= 1 && H >= 1 && W >= 1, "bad shape");
+  RoiWs w = carve_roi(d_ws);
+  UOC_REQUIRE(ws_bytes >= w.total, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int n = H * W;
+  for (int b = 0; b < B; ++b) {
+    int *lab = d_labels + (size_t)b * n;
+    UOC_HIP_CHECK(hipMemsetAsync(w.stats, 0, NL * NSTAT * sizeof(int), st));
+    hipLaunchKernelGGL(label_stats_kernel, dim3(grid_for(n)), dim3(256), 0, st, lab, d_z + (size_t)b * z_batch_stride, H,
+                       W, w.stats);
+    hipLaunchKernelGGL(roi_build_kernel, dim3(1), dim3(NL), 0, st, w.stats, 1, threshold, 0.f, H, W, w.lut,
+                       (uoc_roi_table *)nullptr);
+    hipLaunchKernelGGL(apply_lut_kernel, dim3(grid_for(n)), dim3(256), 0, st, lab, n, w.lut);
+  }
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+int uoc_roi_build(int32_t *d_labels, const float *d_z, int H, int W, float threshold, float pad_fraction,
+                  uoc_roi_table *d_table, void *d_ws, size_t ws_bytes, void *stream) {
+  UOC_REQUIRE(d_labels && d_table && d_ws, "null pointer");
+  RoiWs w = carve_roi(d_ws);
+  UOC_REQUIRE(ws_bytes >= w.total, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int n = H * W;
+  UOC_HIP_CHECK(hipMemsetAsync(w.stats, 0, NL * NSTAT * sizeof(int), st));
+  UOC_HIP_CHECK(hipMemsetAsync(d_table, 0, sizeof(uoc_roi_table), st));
+  hipLaunchKernelGGL(label_stats_kernel, dim3(grid_for(n)), dim3(256), 0, st, d_labels, d_z, H, W, w.stats);
+  hipLaunchKernelGGL(roi_build_kernel, dim3(1), dim3(NL), 0, st, w.stats, d_z ? 1 : 0, threshold, pad_fraction, H, W,
+                     w.lut, d_table);
+  if (d_z) hipLaunchKernelGGL(apply_lut_kernel, dim3(grid_for(n)), dim3(256), 0, st, d_labels, n, w.lut);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+int uoc_roi_crop(const float *d_rgb, const float *d_xyz, const int32_t *d_labels, int H, int W,
+                 const uoc_roi_table *d_table, int K, int S, float *d_rgb_crops, float *d_xyz_crops,
+                 float *d_mask_crops, void *stream) {
+  UOC_REQUIRE(d_rgb && d_xyz && d_labels && d_table && d_rgb_crops && d_xyz_crops && d_mask_crops, "null pointer");
+  UOC_REQUIRE(K >= 1 && K < NL && S >= 1, "K=%d S=%d out of range", K, S);
+  hipLaunchKernelGGL(roi_crop_kernel, dim3((S * S + 255) / 256, K), dim3(256), 0, (hipStream_t)stream, d_rgb, d_xyz,
+                     d_labels, H, W, d_table, S, d_rgb_crops, d_xyz_crops, d_mask_crops);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+int uoc_roi_match_stats(const int32_t *d_labels_crop, const float *d_mask_crops, const float *d_xyz_crops, int K,
+                        int S, int32_t *d_keep, float *d_meanz, void *d_ws, size_t ws_bytes, void *stream) {
+  UOC_REQUIRE(d_labels_crop && d_mask_crops && d_xyz_crops && d_keep && d_meanz && d_ws, "null pointer");
+  UOC_REQUIRE(K >= 1 && K < NL && S >= 1, "K=%d S=%d out of range", K, S);
+  RoiWs w = carve_roi(d_ws);
+  UOC_REQUIRE(ws_bytes >= w.total, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  UOC_HIP_CHECK(hipMemsetAsync(w.cnt, 0, (size_t)K * NL * sizeof(int), st));
+  UOC_HIP_CHECK(hipMemsetAsync(w.ov, 0, (size_t)K * NL * sizeof(int), st));
+  int gb = (S * S + 255) / 256;
+  if (gb > 64) gb = 64;
+  hipLaunchKernelGGL(crop_stats_kernel, dim3(gb, K), dim3(256), 0, st, d_labels_crop, d_mask_crops, S * S, w.cnt, w.ov);
+  hipLaunchKernelGGL(crop_meanz_kernel, dim3(K), dim3(256), 0, st, d_labels_crop, d_xyz_crops, S * S, w.cnt, w.ov,
+                     d_keep, d_meanz);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+int uoc_roi_paste(const int32_t *d_labels_crop, const uoc_roi_table *d_table, const int32_t *d_map,
+                  const int32_t *d_order, int K, int S, int H, int W, int32_t *d_refined, void *stream) {
+  UOC_REQUIRE(d_labels_crop && d_table && d_map && d_order && d_refined, "null pointer");
+  UOC_REQUIRE(K >= 1 && K < NL, "K=%d out of range", K);
+  hipLaunchKernelGGL(paste_kernel, dim3(grid_for(H * W)), dim3(256), 0, (hipStream_t)stream, d_labels_crop, d_table,
+                     d_map, d_order, K, S, H, W, d_refined);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+"""Host-side mirror of the reference's lib/fcn/test_dataset.py inference surface
+(clustering_features :44, crop_rois :62, match_label_crop :116, filter_labels_depth :183,
+test_sample :232, test_segnet :271), backed by libuoc_hip.so.
+
+Same names, argument meaning and return conventions as the reference (labels are float32
+tensors, `out_label` lives on the CPU, ROIs are [K,4] float x0,y0,x1,y1 inclusive, the global
+NumPy RNG is consumed once per clustered field in the reference's order).  Internally labels stay
+int32 on the device and the per-object Python loops of the reference are single batched launches.
+There is no CPU fallback: inputs are moved to the ROCm device and every stage runs as HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import time
+
+import numpy as np
+import torch
+
+from .. import _native
+from ..utils.mean_shift import cluster_batch
+from .config import cfg, require_supported
+
+KAPPA = 20            # test_dataset.py:51
+MAX_ITERS = 10        # :56
+PAD_FRACTION = 0.25   # :66
+DEPTH_FILTER = 0.8    # :252
+MAX_LABELS = 128
+
+_roi_ws = {}
+
+
+def _device():
+    if cfg.device is not None and torch.device(cfg.device).type == "cuda":
+        return torch.device(cfg.device)
+    if not torch.cuda.is_available():
+        raise _native.NativeError("no ROCm device visible: the HIP path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _ws(dev):
+    key = (dev.type, dev.index)
+    if key not in _roi_ws:
+        _roi_ws[key] = torch.empty(_native.lib().uoc_roi_workspace_bytes() + 256, dtype=torch.uint8, device=dev)
+    return _roi_ws[key]
+
+
+def _pixel_major(features: torch.Tensor) -> torch.Tensor:
+    """[B,C,h,w] -> [B,h*w,C] contiguous; zero-copy for the channels-last view SEGNET.forward returns."""
+    B, C, h, w = features.shape
+    x = features.permute(0, 2, 3, 1)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    return x.reshape(B, h * w, C)
+
+
+def _cluster_device(features: torch.Tensor, num_seeds: int = 100):
+    """Device-resident clustering of every batch item: int32 labels [B, h*w], indices [B, m]."""
+    require_supported()
+    if not features.is_cuda:
+        raise _native.NativeError("features must be on a ROCm device (no CPU fallback)")
+    X = _pixel_major(features.float())
+    B, n, _ = X.shape
+    firsts = [np.random.randint(0, n) for _ in range(B)]   # mean_shift.py:155, one draw per field, in order
+    return cluster_batch(X, firsts, KAPPA, num_seeds, MAX_ITERS, 2 * cfg.TRAIN.EMBEDDING_ALPHA)
+
+
+def clustering_features(features, num_seeds=100):
+    """test_dataset.py:44-59 -> (out_label [B,h,w] float32 on the CPU, list of [m] int64 seed indices)."""
+    labels, indices = _cluster_device(features, num_seeds)
+    B, _, h, w = features.shape
+    out_label = labels.view(B, h, w).float().cpu()
+    return out_label, [indices[j].long().cpu() for j in range(B)]
+
+
+def _labels_to_device(labels: torch.Tensor, dev) -> torch.Tensor:
+    lab = labels.to(dev)
+    if lab.dtype != torch.int32:
+        lab = lab.round().to(torch.int32)
+    lab = lab.contiguous()
+    if lab.numel() and (int(lab.max()) >= MAX_LABELS or int(lab.min()) < 0):
+        raise ValueError(f"label ids must be in [0, {MAX_LABELS})")
+    return lab
+
+
+def filter_labels_depth(labels, depth, threshold):
+    """test_dataset.py:183-198.  Returns a new tensor like `labels`."""
+    dev = depth.device if depth.is_cuda else _device()
+    lab = _labels_to_device(labels, dev).clone()
+    d = depth.to(dev).float().contiguous()
+    B, H, W = lab.shape
+    L = _native.lib()
+    ws = _ws(dev)
+    zptr = ctypes.c_void_p(d.data_ptr() + 2 * H * W * 4)
+    with torch.cuda.device(dev):
+        rc = L.uoc_filter_labels_depth(_native.ptr(lab), zptr, 3 * H * W, B, H, W, float(threshold), _native.ptr(ws),
+                                       ws.numel(), _native.stream_ptr(dev))
+    _native.check(rc, "uoc_filter_labels_depth")
+    return lab.to(labels.dtype).to(labels.device)
+
+
+def _read_table(table_dev: torch.Tensor) -> _native.RoiTable:
+    host = table_dev.cpu().numpy().tobytes()      # one small D2H (2.5 KB); synchronises the stream
+    return _native.RoiTable.from_buffer_copy(host)
+
+
+def _build_rois(lab0: torch.Tensor, z_plane_ptr, H, W, dev, threshold=DEPTH_FILTER):
+    L = _native.lib()
+    table = torch.empty(_native.ROI_TABLE_BYTES, dtype=torch.uint8, device=dev)
+    ws = _ws(dev)
+    with torch.cuda.device(dev):
+        rc = L.uoc_roi_build(_native.ptr(lab0), z_plane_ptr, H, W, float(threshold), PAD_FRACTION, _native.ptr(table),
+                             _native.ptr(ws), ws.numel(), _native.stream_ptr(dev))
+    _native.check(rc, "uoc_roi_build")
+    return table
+
+
+def _crop(rgb, depth, lab0, table, K, H, W, dev):
+    S = cfg.TRAIN.SYN_CROP_SIZE
+    L = _native.lib()
+    rgb_crops = torch.empty((K, 3, S, S), dtype=torch.float32, device=dev)
+    depth_crops = torch.empty((K, 3, S, S), dtype=torch.float32, device=dev)
+    mask_crops = torch.empty((K, S, S), dtype=torch.float32, device=dev)
+    if K > 0:
+        with torch.cuda.device(dev):
+            rc = L.uoc_roi_crop(_native.ptr(rgb), _native.ptr(depth), _native.ptr(lab0), H, W, _native.ptr(table), K, S,
+                                _native.ptr(rgb_crops), _native.ptr(depth_crops), _native.ptr(mask_crops),
+                                _native.stream_ptr(dev))
+        _native.check(rc, "uoc_roi_crop")
+    return rgb_crops, mask_crops, depth_crops
+
+
+def crop_rois(rgb, initial_masks, depth):
+    """test_dataset.py:62-112 -> (rgb_crops [K,3,S,S], mask_crops [K,S,S], rois [K,4], depth_crops)."""
+    if depth is None:
+        raise NotImplementedError("RGB-D path only: depth must be given")
+    dev = rgb.device if rgb.is_cuda else _device()
+    rgb = rgb.to(dev).float().contiguous()
+    depth = depth.to(dev).float().contiguous()
+    N, H, W = initial_masks.shape
+    lab0 = _labels_to_device(initial_masks[0], dev)
+    table = _build_rois(lab0, ctypes.c_void_p(0), H, W, dev)
+    t = _read_table(table)
+    K = int(t.K)
+    rgb_crops, mask_crops, depth_crops = _crop(rgb, depth, lab0, table, K, H, W, dev)
+    rois = torch.tensor([[t.box[k][i] for i in range(4)] for k in range(K)], dtype=torch.float32, device=dev).reshape(K, 4)
+    return rgb_crops, mask_crops, rois, depth_crops
+
+
+def _order_and_map(keep: np.ndarray, meanz: torch.Tensor):
+    """Host part of match_label_crop: ROI paint order by mean depth, far first (:150-151, Python's
+    stable sort with reverse=True on the 0-dim tensors, NaN behaviour included) and the global
+    renumbering of kept clusters in that order (:156-163)."""
+    K = keep.shape[0]
+    keys = [(i, meanz[i]) for i in range(K)]
+    order = [i for i, _ in sorted(keys, key=lambda kv: kv[1], reverse=True)]
+    mapping = np.zeros((K, MAX_LABELS), dtype=np.int32)
+    count = 0
+    for i in order:
+        for c in np.nonzero(keep[i])[0]:
+            count += 1
+            mapping[i, c] = count
+    return np.asarray(order, dtype=np.int32), mapping
+
+
+def _match(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev):
+    """labels_crop_i32 [K, S*S] int32 (device) -> refined int32 [H*W] (device), keep table (host)."""
+    S = cfg.TRAIN.SYN_CROP_SIZE
+    L = _native.lib()
+    ws = _ws(dev)
+    keep = torch.empty((K, MAX_LABELS), dtype=torch.int32, device=dev)
+    meanz = torch.empty((K,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.uoc_roi_match_stats(_native.ptr(labels_crop_i32), _native.ptr(mask_crops), _native.ptr(depth_crops), K, S,
+                                   _native.ptr(keep), _native.ptr(meanz), _native.ptr(ws), ws.numel(),
+                                   _native.stream_ptr(dev))
+    _native.check(rc, "uoc_roi_match_stats")
+    keep_h = keep.cpu().numpy()
+    order, mapping = _order_and_map(keep_h, meanz.cpu())
+    order_d = torch.from_numpy(order).to(dev)
+    map_d = torch.from_numpy(mapping).to(dev)
+    refined = torch.empty((H * W,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.uoc_roi_paste(_native.ptr(labels_crop_i32), _native.ptr(table), _native.ptr(map_d), _native.ptr(order_d),
+                             K, S, H, W, _native.ptr(refined), _native.stream_ptr(dev))
+    _native.check(rc, "uoc_roi_paste")
+    return refined, keep
+
+
+def match_label_crop(initial_masks, labels_crop, out_label_crop, rois, depth_crop):
+    """test_dataset.py:116-179 -> (refined_masks like initial_masks (float), labels_crop with rejected = -1)."""
+    if depth_crop is None:
+        raise NotImplementedError("RGB-D path only: depth_crop must be given")
+    dev = labels_crop.device if labels_crop.is_cuda else _device()
+    K = labels_crop.shape[0]
+    N, H, W = initial_masks.shape
+    refined_masks = torch.zeros_like(initial_masks).float()
+    if K == 0:
+        return refined_masks, labels_crop
+    lab = _labels_to_device(labels_crop, dev).reshape(K, -1)
+    t = _native.RoiTable()
+    t.K = K
+    r = rois.detach().cpu().numpy().astype(np.int64)
+    for k in range(K):
+        for i in range(4):
+            t.box[k][i] = int(r[k, i])
+    table = torch.frombuffer(bytearray(bytes(t)), dtype=torch.uint8).to(dev)
+    refined, keep = _match(lab, out_label_crop.to(dev).float().contiguous(), depth_crop.to(dev).float().contiguous(),
+                           table, K, H, W, dev)
+    refined_masks[0] = refined.view(H, W).float().to(refined_masks.device)
+    kept = torch.gather(keep, 1, lab.long()) != 0
+    labels_out = torch.where(kept, lab, torch.full_like(lab, -1)).view(labels_crop.shape).to(labels_crop.dtype)
+    return refined_masks, labels_out.to(labels_crop.device)
+
+
+def test_sample(sample, network, network_crop):
+    """test_dataset.py:232-267: (out_label [B,H,W] float32 CPU, out_label_refined [1,H,W] float32 CPU or None)."""
+    return _run_frame(sample, network, network_crop, DEPTH_FILTER)
+
+
+def _run_frame(sample, network, network_crop, depth_threshold):
+    """Per-frame body shared by test_sample (:247-261) and test_segnet (:288-321).
+    depth_threshold None = no depth-coverage filter."""
+    require_supported()
+    dev = _device()
+    image = sample["image_color"].to(dev).float().contiguous()
+    depth = sample["depth"].to(dev).float().contiguous()
+    label = sample["label"].to(dev) if "label" in sample else None
+    B, _, H, W = image.shape
+
+    features = network(image, label, depth).detach()
+    labels, _ = _cluster_device(features, num_seeds=100)                 # [B, H*W] int32 on the device
+
+    # depth filter (:250-252) fused with the ROI table build for item 0; other items filter only
+    zptr = ctypes.c_void_p(depth.data_ptr() + 2 * H * W * 4) if depth_threshold is not None else ctypes.c_void_p(0)
+    table = _build_rois(labels[0], zptr, H, W, dev, depth_threshold if depth_threshold is not None else 0.0)
+    if B > 1 and depth_threshold is not None:
+        L = _native.lib()
+        ws = _ws(dev)
+        z1 = ctypes.c_void_p(depth.data_ptr() + (3 * H * W + 2 * H * W) * 4)
+        with torch.cuda.device(dev):
+            _native.check(L.uoc_filter_labels_depth(_native.ptr(labels[1:]), z1, 3 * H * W, B - 1, H, W, float(depth_threshold),
+                                                    _native.ptr(ws), ws.numel(), _native.stream_ptr(dev)),
+                          "uoc_filter_labels_depth")
+
+    out_label_refined = None
+    if network_crop is not None:
+        K = int(_read_table(table).K)
+        if K > 0:
+            rgb_crop, mask_crop, depth_crop = _crop(image, depth, labels[0], table, K, H, W, dev)
+            features_crop = network_crop(rgb_crop, mask_crop, depth_crop)
+            labels_crop, _ = _cluster_device(features_crop)              # K fields, one launch set
+            refined, _ = _match(labels_crop, mask_crop, depth_crop, table, K, H, W, dev)
+            out_label_refined = refined.view(1, H, W).float().cpu()
+    out_label = labels.view(B, H, W).float().cpu()
+    return out_label, out_label_refined
+
+
+def test_segnet(test_loader, network, output_dir, network_crop):
+    """test_dataset.py:271-381: dataset loop around the same per-frame body; writes one .mat per
+    sample (labels, labels_refined, filename) like the reference (:337-340).  The P/R/F metric
+    printout (:308-329,346-381) needs the datasets/evaluation stack that is outside this path."""
+    import scipy.io
+    network.eval()
+    if network_crop is not None:
+        network_crop.eval()
+    epoch_size = len(test_loader)
+    results = []
+    name = str(getattr(getattr(test_loader, "dataset", None), "name", ""))
+    threshold = 0.5 if "ocid" in name else (0.8 if "osd" in name else None)      # :299-305
+    for i, sample in enumerate(test_loader):
+        end = time.time()
+        out_label, out_label_refined = _run_frame(sample, network, network_crop, threshold)
+        prediction = out_label.squeeze().numpy()
+        prediction_refined = out_label_refined.squeeze().numpy() if out_label_refined is not None else prediction.copy()
+        result = {"labels": prediction, "labels_refined": prediction_refined, "filename": sample.get("filename", "")}
+        if output_dir is not None:
+            filename = os.path.join(output_dir, "%06d.mat" % i)
+            scipy.io.savemat(filename, result, do_compression=True)
+        results.append(result)
+        print("[%d/%d], batch time %.2f" % (i, epoch_size, time.time() - end))
+    return results
