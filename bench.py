@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: end-to-end two-stage RGB-D segmentation at 640x480.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W            (N > 1)
+
+One step = one synthetic 640x480 RGB-D frame (batch 1) through the whole path on one GPU:
+RGB-D ResNet34-8s embedding -> mean-shift (100 seeds, 10 iterations) -> depth filter -> ROI
+crops -> second network on the K crops -> K batched mean-shifts -> match/paste (BASELINE.json
+configs[3]; configs[4] = the same sharded over N GPUs with one RCCL all_gather of the label maps).
+Inputs are resident in HBM when the timed region starts; the timed region includes the D2H of
+the label-map block.  Weights are the calibrated synthetic set (synth.calibrated_state_dict):
+random-init backbone of the reference architecture + closed-form calibration so that synthetic
+frames segment into their objects and stage 2 really runs (K ~ 6-8 ROIs per frame).
+
+Prints ONE JSON line (rank 0).  `roofline` = the kernel class with the largest share of GPU time
+in a profiled pass over the same frames (HIP events on the launch stream, csrc/prof.hip);
+`cpu_baseline` = the CPU oracle (torch CPU restatement of the reference path) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H, W = 480, 640
+PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (= vector) peak
+
+
+def make_samples(count, first_seed, device):
+    from unseenobjectclustering_amd import synth
+    out = []
+    for i in range(count):
+        s = first_seed + i
+        fr = synth.palette_frame(s, H, W, 5 + s % 3)
+        out.append(dict(image_color=torch.from_numpy(fr["image_color"]).to(device),
+                        depth=torch.from_numpy(fr["depth"]).to(device)))
+    return out
+
+
+def cpu_baseline(frames):
+    """The oracle's two-stage test_sample on the host cores (torch CPU ops = the reference's ops)."""
+    from oracle import backbone_oracle as BO, glue_oracle as GO
+    from unseenobjectclustering_amd import synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    net = lambda img, label, depth: BO.segnet_forward(sd, img, depth)
+    t0 = time.time()
+    for i in range(frames):
+        fr = synth.palette_frame(i, H, W, 5 + i % 3)
+        GO.test_sample(torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"]), net, net,
+                       np.random.RandomState(3 + i))
+    dt = time.time() - t0
+    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{frames} synthetic 640x480 RGB-D frames, full two-stage path, oracle/ (torch CPU fp32)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames for the CPU baseline (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device: the product path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from unseenobjectclustering_amd import _native, networks, runner, synth
+    from unseenobjectclustering_amd.fcn.config import cfg
+    cfg.device = device
+
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    network = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    network_crop = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+
+    K = args.steps
+    distinct = min(K, 8)
+    samples = make_samples(distinct, 10_000 + rank * distinct, device)     # each rank gets its own frames
+    frame_fn = runner.two_stage_frame_fn(samples, network, network_crop)
+
+    def run(nsteps, gather):
+        # frames of this rank: global indices rank*nsteps .. (weak scaling: fixed work per GPU)
+        total = nsteps * world
+        maps = runner.run_sharded(total, lambda i: frame_fn(i - rank * nsteps), H, W, device, rank, world, gather)
+        return maps.cpu()           # label-map block lands on the host inside the timed region
+
+    if args.warmup > 0:
+        run(args.warmup, world > 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    maps = run(K, world > 1)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    objects = float(np.mean([int(m.max()) for m in maps[:K]]))
+
+    # ---- profiled pass (HIP events around every launch; separate from the timed region) ----
+    roof, kernels = None, []
+    if rank == 0 and args.profile_steps > 0:
+        _native.prof_enable(True)
+        for i in range(args.profile_steps):
+            np.random.seed(runner.frame_rng_seed(i))
+            frame_fn(i)
+        torch.cuda.synchronize()
+        rep = _native.prof_report()
+        _native.prof_enable(False)
+        tot = sum(r["total_ms"] for r in rep) or 1.0
+        for r in sorted(rep, key=lambda r: -r["total_ms"]):
+            sec = r["total_ms"] / 1e3
+            kernels.append({"kernel": r["kernel"], "launches_per_frame": r["launches"] / args.profile_steps,
+                            "avg_us": round(1e3 * r["total_ms"] / r["launches"], 2),
+                            "gpu_time_share": round(r["total_ms"] / tot, 4),
+                            "tflops": round(r["flops"] / sec / 1e12, 2), "gbs": round(r["bytes"] / sec / 1e9, 1)})
+        dom = max(rep, key=lambda r: r["total_ms"])
+        sec = dom["total_ms"] / 1e3
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(dom["kernel"])
+        if dom["kernel"].startswith("conv") or dom["kernel"] in ("hc_iter", "assign"):
+            ach = dom["flops"] / sec / 1e12
+            roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                    "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2)}
+        else:
+            ach = dom["bytes"] / sec / 1e9
+            roof = {"kernel": dom["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        cpu = cpu_baseline(args.cpu_frames)
+
+    if rank == 0:
+        line = {
+            "metric": "frames/sec at 640x480 RGB-D, two-stage clustering",
+            "value": round(K * world / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[3]: full two-stage (crop-and-refine) segmentation, 640x480 RGB-D, batch 1"
+                                   + ("" if world == 1 else f"; configs[4]: frames sharded over {world} GPUs + RCCL all_gather"),
+                       "frame": "640x480", "seeds": 100, "iters": 10, "crop": 224,
+                       "mean_final_objects": round(objects, 2), "frames_per_gpu": K},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

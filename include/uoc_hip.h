@@ -139,6 +139,16 @@ int uoc_roi_match_stats(const int32_t *d_labels_crop, const float *d_mask_crops,
 int uoc_roi_paste(const int32_t *d_labels_crop, const uoc_roi_table *d_table, const int32_t *d_map,
                   const int32_t *d_order, int K, int S, int H, int W, int32_t *d_refined, void *stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Opt-in per-kernel timing (HIP events on the launch stream).  Single-threaded use.
+ * uoc_prof_report writes a JSON array [{kernel, launches, total_ms, flops, bytes}, ...] where
+ * flops/bytes are the ALGORITHMIC totals of the recorded launches.
+ * ---------------------------------------------------------------------------------------- */
+int uoc_prof_enable(int on);
+int uoc_prof_reset(void);
+int uoc_prof_report(char *buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

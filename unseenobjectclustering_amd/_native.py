@@ -46,6 +46,11 @@ def _declare(lib):
     lib.uoc_roi_paste.argtypes = [P, P, P, P, c_int, c_int, c_int, c_int, P, P]
     for name in ("uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats", "uoc_roi_paste"):
         getattr(lib, name).restype = c_int
+    lib.uoc_prof_enable.argtypes = [c_int]
+    lib.uoc_prof_reset.argtypes = []
+    lib.uoc_prof_report.argtypes = [ctypes.c_char_p, c_size_t]
+    for name in ("uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report"):
+        getattr(lib, name).restype = c_int
     for name in ("uoc_ms_select_seeds", "uoc_ms_hill_climb", "uoc_ms_seed_components", "uoc_ms_assign",
                  "uoc_ms_cluster"):
         getattr(lib, name).restype = c_int
@@ -58,7 +63,7 @@ EXPORTED_SYMBOLS = (
     "uoc_net_create", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",
     "uoc_net_forward", "uoc_conv2d_nhwc",
     "uoc_roi_workspace_bytes", "uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats",
-    "uoc_roi_paste",
+    "uoc_roi_paste", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
 )
 
 
@@ -99,3 +104,16 @@ def ptr(t):
 def stream_ptr(device=None):
     import torch
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def prof_enable(on: bool):
+    lib().uoc_prof_reset()
+    lib().uoc_prof_enable(1 if on else 0)
+
+
+def prof_report():
+    """Per-kernel-class totals recorded since prof_enable(True): list of dicts."""
+    import json
+    buf = ctypes.create_string_buffer(1 << 16)
+    check(lib().uoc_prof_report(buf, len(buf)), "uoc_prof_report")
+    return json.loads(buf.value.decode())

@@ -16,6 +16,7 @@
 // With weights as the MFMA "A" operand, each lane ends up holding 4 CONSECUTIVE output channels
 // of one pixel, so the epilogue is float4 loads/stores in NHWC.
 #include "conv.h"
+#include "prof.h"
 
 #include <stdlib.h>
 
@@ -206,8 +207,13 @@ constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kNumCU = 256;
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
-static int launch_cfg(const ConvParams &p, hipStream_t st) {
+static int launch_cfg(const ConvParams &p, hipStream_t st, int kc) {
   const int M = p.B * p.Ho * p.Wo;
+  const double taps = (double)p.KH * p.KW;
+  const double flops = 2.0 * M * p.Cout * (STEM ? 3.0 : (double)p.Cin) * taps * p.G;
+  const double bytes = 4.0 * p.G * ((double)p.B * p.H * p.W * (STEM ? 3 : p.Cin) + taps * p.Cout * (STEM ? 3 : p.Cin) +
+                                    (double)M * p.Cout * (p.res ? 2 : 1));
+  ProfScope prof(kc, st, flops, bytes);
   const int mtiles = (M + BM - 1) / BM, ntiles = p.Cout / BN;
   const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
   static bool attr_set = false;
@@ -253,15 +259,15 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   if (p.stem) {
     UOC_REQUIRE(p.Cin == 4 && p.KH == 7 && p.KW == 7 && p.stride == 2 && p.pad == 3 && p.dil == 1 && p.Cout == 64,
                 "conv: stem path is 7x7 s2 p3, NHWC4 -> 64 only");
-    return launch_cfg<160, 64, 2, 4, true>(p, st);
+    return launch_cfg<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
   }
   UOC_REQUIRE(p.Cin % BK == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, BK);
   UOC_REQUIRE(p.Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", p.Cout);
   switch (pick_cfg(p)) {
-    case 0: return launch_cfg<160, 128, 2, 4, false>(p, st);
-    case 1: return launch_cfg<80, 128, 1, 8, false>(p, st);
-    case 2: return launch_cfg<160, 64, 2, 4, false>(p, st);
-    case 3: return launch_cfg<80, 64, 1, 4, false>(p, st);
+    case 0: return launch_cfg<160, 128, 2, 4, false>(p, st, KC_CONV_160x128);
+    case 1: return launch_cfg<80, 128, 1, 8, false>(p, st, KC_CONV_80x128);
+    case 2: return launch_cfg<160, 64, 2, 4, false>(p, st, KC_CONV_160x64);
+    case 3: return launch_cfg<80, 64, 1, 4, false>(p, st, KC_CONV_80x64);
   }
   set_error("conv: no tile configuration for Cout=%d", p.Cout);
   return UOC_EINVAL;
@@ -281,6 +287,7 @@ int launch_nchw3_to_nhwc4(const float *in, float *out, int B, int H, int W, hipS
   const int total = B * H * W;
   int blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
+  ProfScope prof(KC_NET_MISC, st, 0.0, 28.0 * total);
   hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(blocks), dim3(256), 0, st, in, out, H * W, total);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
@@ -321,6 +328,7 @@ int launch_maxpool3x3s2(const float *in, float *out, int n_img, int H, int W, in
   const int total = n_img * Ho * Wo * (C / 4);
   int blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
+  ProfScope prof(KC_NET_MISC, st, 0.0, 4.0 * ((double)n_img * H * W * C + (double)total * 4));
   hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, st, in, out, H, W, C / 4, Ho, Wo, total);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
@@ -384,6 +392,7 @@ int launch_head(const float *fa, const float *fb, float *embed, int B, int h, in
   long blocks = (total / 4 + 3) / 4;  // 4 waves per block, 4 pixels per wave step
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
+  ProfScope prof(KC_HEAD, st, 0.0, 4.0 * 64 * ((double)total + 2.0 * B * h * w));
   hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fa, fb, embed, B, h, w, H, W, sy, sx);
   UOC_LAUNCH_CHECK();
   return UOC_OK;

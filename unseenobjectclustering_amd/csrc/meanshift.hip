@@ -11,6 +11,7 @@
 // Data layout: X is pixel-major [batch][n][64] fp32 (256 B per pixel), seeds Z [batch][m][64].
 // All reductions have a fixed order, so results are run-to-run deterministic.
 #include "common.h"
+#include "prof.h"
 
 #include <limits.h>
 #include <math.h>
@@ -565,6 +566,8 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
   const int nblk = fps_blocks(n);
   for (int s = 0; s < m; ++s) {
     dim3 grid(nblk, batch);  // gridDim.x doubles as the partial count, so it is the same every step
+    const bool last = s == m - 1;
+    ProfScope prof(KC_FPS_STEP, st, last ? 0.0 : 2.0 * batch * n * C, last ? 0.0 : 4.0 * batch * ((double)n * C + 2.0 * n));
     hipLaunchKernelGGL(fps_step_kernel, grid, dim3(FPS_THREADS), 0, st, X, n, m, s, first, w.dmin, seeds, indices,
                        w.part[(s + 1) & 1], w.part[s & 1]);
   }
@@ -579,8 +582,12 @@ static void launch_hc(const float *X, int batch, int n, float *Z, int m, float k
   const size_t rbytes = (size_t)2 * ST * 4 * 64 * sizeof(f32x4);
   const size_t lds = zbytes > rbytes ? zbytes : rbytes;
   for (int it = 0; it < iters; ++it) {
-    hipLaunchKernelGGL(hc_iter_kernel<ST>, dim3(w.hc_nblk, batch), dim3(HC_THREADS), lds, st, X, n, Z, m, kappa,
-                       w.hc_partial);
+    {
+      ProfScope prof(KC_HC_ITER, st, 4.0 * batch * m * (double)n * C, 4.0 * batch * ((double)n * C + 2.0 * m * C));
+      hipLaunchKernelGGL(hc_iter_kernel<ST>, dim3(w.hc_nblk, batch), dim3(HC_THREADS), lds, st, X, n, Z, m, kappa,
+                         w.hc_partial);
+    }
+    ProfScope prof(KC_HC_FINALIZE, st, 0.0, 4.0 * batch * w.hc_nblk * ST * 16.0 * C);
     hipLaunchKernelGGL(hc_finalize_kernel, dim3(m, batch), dim3(256), 0, st, w.hc_partial, w.hc_nblk, ST * 16, m, Z);
   }
 }
@@ -607,6 +614,7 @@ static void launch_assign(const float *X, int batch, int n, const float *Z, cons
   int nblk = hc_blocks(batch, n) * 2;
   const int maxb = ((n + 15) / 16 + 3) / 4;
   if (nblk > maxb) nblk = maxb;
+  ProfScope prof(KC_ASSIGN, st, 2.0 * batch * m * (double)n * C, 4.0 * batch * ((double)n * C + n));
   hipLaunchKernelGGL(assign_kernel<ST>, dim3(nblk, batch), dim3(HC_THREADS), 0, st, X, n, Z, seed_labels, m, labels,
                      closest, w.counts);
 }
@@ -627,6 +635,7 @@ static int run_assign(const float *X, int batch, int n, const float *Z, const in
   }
   int rb = (n + 255) / 256;
   if (rb > 512) rb = 512;
+  ProfScope prof(KC_RELABEL, st, 0.0, 8.0 * batch * n);
   hipLaunchKernelGGL(relabel_swap_kernel, dim3(rb, batch), dim3(256), 0, st, labels, n, w.counts, num_unique);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
@@ -691,7 +700,10 @@ int uoc_ms_cluster(const float *d_X, int batch, int n, int m, float kappa, int i
   int *sl = d_seed_labels_out ? d_seed_labels_out : w.seed_labels;
   if (int rc = run_select_seeds(d_X, batch, n, m, d_first_index, Z, d_indices, w, st)) return rc;
   if (int rc = run_hill_climb(d_X, batch, n, Z, m, kappa, iters, w, st)) return rc;
-  hipLaunchKernelGGL(seed_cc_kernel, dim3(batch), dim3(64), 0, st, Z, m, epsilon, sl, w.num_unique);
+  {
+    ProfScope prof(KC_SEED_CC, st, 0.0, 4.0 * batch * m * C);
+    hipLaunchKernelGGL(seed_cc_kernel, dim3(batch), dim3(64), 0, st, Z, m, epsilon, sl, w.num_unique);
+  }
   UOC_LAUNCH_CHECK();
   return run_assign(d_X, batch, n, Z, sl, w.num_unique, m, d_labels, nullptr, w, st);
 }

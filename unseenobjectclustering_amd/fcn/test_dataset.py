@@ -218,9 +218,10 @@ def test_sample(sample, network, network_crop):
     return _run_frame(sample, network, network_crop, DEPTH_FILTER)
 
 
-def _run_frame(sample, network, network_crop, depth_threshold):
+def _run_frame(sample, network, network_crop, depth_threshold, return_device=False):
     """Per-frame body shared by test_sample (:247-261) and test_segnet (:288-321).
-    depth_threshold None = no depth-coverage filter."""
+    depth_threshold None = no depth-coverage filter.  return_device=True keeps the int32 label
+    maps on the device ([B,H,W], [1,H,W] or None) for the frame-parallel runner."""
     require_supported()
     dev = _device()
     image = sample["image_color"].to(dev).float().contiguous()
@@ -251,8 +252,12 @@ def _run_frame(sample, network, network_crop, depth_threshold):
             features_crop = network_crop(rgb_crop, mask_crop, depth_crop)
             labels_crop, _ = _cluster_device(features_crop)              # K fields, one launch set
             refined, _ = _match(labels_crop, mask_crop, depth_crop, table, K, H, W, dev)
-            out_label_refined = refined.view(1, H, W).float().cpu()
+            out_label_refined = refined.view(1, H, W)
+    if return_device:
+        return labels.view(B, H, W), out_label_refined
     out_label = labels.view(B, H, W).float().cpu()
+    if out_label_refined is not None:
+        out_label_refined = out_label_refined.float().cpu()
     return out_label, out_label_refined
 
 

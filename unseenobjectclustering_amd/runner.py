@@ -1,0 +1,58 @@
+"""Frame-parallel runner: frames are independent units, so they shard across ranks (one process
+per GPU, torch.distributed; backend 'nccl' = RCCL over xGMI on the GPU node, 'gloo' in CPU tests)
+with no communication during compute and ONE all_gather of the fixed-size per-rank label-map
+block at the end.  The reference has no counterpart (inference pins one device,
+tools/test_images.py:199).
+
+Sharding-independent results: the NumPy RNG that picks the first mean-shift seed
+(mean_shift.py:155) is re-seeded per frame from the GLOBAL frame index.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .fcn.config import cfg
+
+
+def shard_range(num_frames: int, rank: int, world: int):
+    """Contiguous block [lo, hi) of ceil(F/G) frames for `rank` (last blocks may be short/empty)."""
+    per = (num_frames + world - 1) // world
+    lo = min(rank * per, num_frames)
+    return lo, min(lo + per, num_frames)
+
+
+def frame_rng_seed(frame_index: int) -> int:
+    return int(cfg.RNG_SEED) + int(frame_index)
+
+
+def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height: int, width: int,
+                device: torch.device, rank: int = 0, world: int = 1, gather: bool = True) -> Optional[torch.Tensor]:
+    """Runs frame_fn(global_index) -> [H,W] integer label map (on `device`) for this rank's block
+    and all-gathers the uint8 blocks.  Returns [num_frames, H, W] uint8 on `device` (every rank),
+    or only the local block when gather=False / world == 1."""
+    per = (num_frames + world - 1) // world
+    lo, hi = shard_range(num_frames, rank, world)
+    block = torch.zeros((per, height, width), dtype=torch.uint8, device=device)
+    for i in range(lo, hi):
+        np.random.seed(frame_rng_seed(i))
+        block[i - lo] = frame_fn(i).to(torch.uint8)
+    if world == 1 or not gather:
+        return block[:hi - lo]
+    full = torch.empty((world * per, height, width), dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(full, block)
+    return full[:num_frames]
+
+
+def two_stage_frame_fn(samples, network, network_crop):
+    """frame_fn over pre-uploaded samples: final label map = refined map if stage 2 produced one,
+    else the stage-1 map (what test_segnet stores as labels_refined, test_dataset.py:324-327)."""
+    from .fcn.test_dataset import _run_frame, DEPTH_FILTER
+
+    def fn(i: int) -> torch.Tensor:
+        out, refined = _run_frame(samples[i % len(samples)], network, network_crop, DEPTH_FILTER, return_device=True)
+        return (refined if refined is not None else out)[0]
+    return fn

@@ -168,3 +168,84 @@ def synthetic_state_dict(seed: int, num_units: int = 64, branches=("fcn", "fcn_d
             else:  # bn bias, running_mean
                 sd[key] = (0.1 * rng.standard_normal(shape)).astype(np.float32)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------
+# Benchmark workload: palette-coloured tabletop frames + "calibrated" synthetic weights.
+#
+# There are no trained checkpoints in the build/bench environment and a randomly initialised
+# network maps every pixel to (almost) the same embedding, which would leave stage 2 of the
+# pipeline without any ROI.  For end-to-end benchmarks the synthetic weights are therefore
+# *calibrated* (scripts/make_calibrated_weights.py, CPU oracle): random backbone, BatchNorm
+# statistics measured on synthetic frames, and the two 1x1 `fc` layers fitted in closed form
+# (ridge regression) so that each palette colour maps to its own embedding direction.  Same
+# architecture, same FLOPs, dense non-zero weights; the frames then segment into their objects.
+# ---------------------------------------------------------------------------------------------
+
+PALETTE_BGR = np.array([
+    [0.15, 0.15, 0.15], [0.55, 0.50, 0.45],                       # background, table
+    [0.85, 0.15, 0.15], [0.15, 0.85, 0.15], [0.15, 0.15, 0.85], [0.85, 0.85, 0.15],
+    [0.85, 0.15, 0.85], [0.15, 0.85, 0.85], [0.90, 0.90, 0.90], [0.90, 0.50, 0.10],
+    [0.10, 0.50, 0.90], [0.50, 0.90, 0.10],
+], dtype=np.float32)
+
+
+def palette_frame(seed: int, height: int = 480, width: int = 640, num_objects: int = 5,
+                  hole_fraction: float = 0.05, colour_noise: float = 0.03):
+    """Like rgbd_frame but colours come from PALETTE_BGR (background 0, table 1, objects drawn
+    without replacement from the rest).  Extra key 'palette' [H,W] int32 = palette index per pixel."""
+    assert num_objects <= len(PALETTE_BGR) - 2
+    fr = rgbd_frame(seed, height, width, num_objects, hole_fraction)
+    lab = fr["label"]
+    rng = np.random.default_rng(611953 * seed + 29)
+    k = int(lab.max()) + 1
+    pal = np.zeros(k, dtype=np.int32)
+    pal[:2] = [0, 1][:k]
+    if k > 2:
+        pal[2:] = 2 + rng.permutation(len(PALETTE_BGR) - 2)[:k - 2]
+    img = PALETTE_BGR[pal][lab] + np.float32(colour_noise) * rng.standard_normal((height, width, 3), dtype=np.float32)
+    img = np.clip(img, 0.0, 1.0).astype(np.float32) - (PIXEL_MEANS / 255.0).astype(np.float32)
+    fr["image_color"] = np.ascontiguousarray(img.transpose(2, 0, 1))[None]
+    fr["palette"] = pal[lab]
+    return fr
+
+
+def _gauss7(sigma: float) -> np.ndarray:
+    a = np.arange(7, dtype=np.float64) - 3.0
+    g = np.exp(-(a[:, None] ** 2 + a[None, :] ** 2) / (2 * sigma * sigma))
+    return (g / g.sum()).astype(np.float32)
+
+
+def uncalibrated_bench_state_dict(seed: int = 0):
+    """Random backbone used as the starting point of the calibration: xavier-normal 3x3/1x1 convs,
+    stem = random 64x3 colour mix (x) 7x7 Gaussian window (sigma 1.5), BN gamma 1 (0.1 on every
+    block's bn2, the usual zero-ish residual init), beta 0, stats 0/1, fc from the generator."""
+    sd = synthetic_state_dict(1000 + seed)
+    rng = np.random.default_rng(2750159 * seed + 7)
+    for br in ("fcn", "fcn_depth"):
+        mix = rng.standard_normal((64, 3)).astype(np.float32)
+        sd[f"{br}.resnet34_8s.conv1.weight"] = (mix[:, :, None, None] * _gauss7(1.5)[None, None]).astype(np.float32)
+    for k in list(sd):
+        is_bn = (".bn" in k or "resnet34_8s.bn1" in k or "downsample.1" in k) and sd[k].ndim == 1
+        if not is_bn:
+            continue
+        if k.endswith("running_mean") or k.endswith(".bias"):
+            sd[k] = np.zeros_like(sd[k])
+        elif k.endswith("running_var"):
+            sd[k] = np.ones_like(sd[k])
+        elif k.endswith(".weight"):
+            sd[k] = np.full_like(sd[k], 0.1 if k.endswith("bn2.weight") else 1.0)
+    return sd
+
+
+def calibrated_state_dict(path: str = None):
+    """uncalibrated_bench_state_dict(0) + the committed calibration (BN stats, fitted fc layers)."""
+    import os
+    if path is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "bench_calibration.npz")
+    sd = uncalibrated_bench_state_dict(0)
+    cal = np.load(path)
+    for k in cal.files:
+        assert k in sd and sd[k].shape == cal[k].shape, k
+        sd[k] = cal[k].astype(np.float32)
+    return sd
