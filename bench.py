@@ -53,17 +53,40 @@ def cpu_baseline(frames):
     """The oracle's two-stage test_sample on the host cores (torch CPU ops = the reference's ops)."""
     from oracle import backbone_oracle as BO, glue_oracle as GO
     from unseenobjectclustering_amd import synth
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 64)))
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
     net = lambda img, label, depth: BO.segnet_forward(sd, img, depth)
+    inputs = [synth.palette_frame(i, H, W, 5 + i % 3) for i in range(frames)]
     t0 = time.time()
-    for i in range(frames):
-        fr = synth.palette_frame(i, H, W, 5 + i % 3)
+    done = 0
+    for i, fr in enumerate(inputs):
         GO.test_sample(torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"]), net, net,
                        np.random.RandomState(3 + i))
+        done += 1
+        if time.time() - t0 > 30.0:          # bounded sample: stop after ~30 s of CPU work
+            break
     dt = time.time() - t0
-    return {"value": round(frames / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{frames} synthetic 640x480 RGB-D frames, full two-stage path, oracle/ (torch CPU fp32)"}
+    return {"value": round(done / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{done} synthetic 640x480 RGB-D frames, full two-stage path, oracle/ (torch CPU fp32)"}
+
+
+def cpu_baseline_subprocess(frames, limit_s=240):
+    """Runs the CPU leg in a child process so a slow host can never stall the GPU benchmark."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(frames)],
+                           capture_output=True, text=True, timeout=limit_s)
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"value": None, "unit": "frames/s", "cores": None, "kind": "port", "sample": "failed: " + r.stderr[-200:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "frames/s", "cores": None, "kind": "port",
+                "sample": f"timed out after {limit_s}s on this host"}
 
 
 def main():
@@ -73,7 +96,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames for the CPU baseline (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=4)
+    ap.add_argument("--cpu-baseline-only", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only > 0:
+        print(json.dumps(cpu_baseline(args.cpu_baseline_only)), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -107,8 +134,10 @@ def main():
         maps = runner.run_sharded(total, lambda i: frame_fn(i - rank * nsteps), H, W, device, rank, world, gather)
         return maps.cpu()           # label-map block lands on the host inside the timed region
 
+    print(f"[bench] rank {rank}: nets built, {distinct} frames resident, warming up", file=sys.stderr, flush=True)
     if args.warmup > 0:
         run(args.warmup, world > 1)
+    print(f"[bench] rank {rank}: warmup done", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -123,6 +152,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     objects = float(np.mean([int(m.max()) for m in maps[:K]]))
+    print(f"[bench] rank {rank}: timed region {dt:.3f}s", file=sys.stderr, flush=True)
 
     # ---- profiled pass (HIP events around every launch; separate from the timed region) ----
     roof, kernels = None, []
@@ -160,7 +190,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
-        cpu = cpu_baseline(args.cpu_frames)
+        cpu = cpu_baseline_subprocess(args.cpu_frames)
 
     if rank == 0:
         line = {

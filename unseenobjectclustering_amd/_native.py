@@ -82,6 +82,10 @@ def lib():
             raise NativeError(
                 f"{LIB_PATH} not found: build it with `python -m unseenobjectclustering_amd.build` "
                 "(or __graft_entry__.build()).  There is no CPU fallback.")
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so); it must be the one the process
+        # loads first, otherwise this library would pull /opt/rocm's copy in and the two runtimes clash
+        # ("no ROCm-capable device is detected").  Importing torch before dlopen guarantees sharing.
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         _declare(l)
         _lib = l
