@@ -23,7 +23,7 @@
 namespace uoc {
 
 constexpr int BK = 32;   // K-chunk (floats)
-constexpr int BKP = 36;  // padded LDS row pitch
+constexpr int BKP = 40;  // padded LDS row pitch: 10 x 16 B => the b128 fragment reads are bank-conflict free
 
 __device__ __forceinline__ f32x4 mfma4c(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -80,88 +80,96 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvPa
     }
   }
 
+  // Software pipeline (one barrier per K-chunk):
+  //   top of chunk kc: the h=0 operand fragments of chunk kc are already in registers (op0);
+  //   issue the global loads of chunk kc+1, prefetch the h=1 fragments (op1) from LDS, run the h=0
+  //   MFMAs (they hide both latencies), park chunk kc+1 in the other LDS stage, barrier, prefetch
+  //   chunk kc+1's h=0 fragments, run the h=1 MFMAs.
+  float4 ra[APASS], rb[BPASS];
+#pragma unroll
+  for (int j = 0; j < APASS; ++j) ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < BPASS; ++j) rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+#define UOC_GLOAD(KN)                                                                                        \
+  {                                                                                                          \
+    const int tap = (KN) / cpt;                                                                              \
+    const int c0 = ((KN)-tap * cpt) * BK;                                                                    \
+    const int kh = STEM ? tap : tap / p.KW;                                                                  \
+    const int kw = STEM ? 0 : tap - kh * p.KW;                                                               \
+    _Pragma("unroll") for (int j = 0; j < APASS; ++j) {                                                      \
+      const int iy = a_iy0[j] + kh * p.dil;                                                                  \
+      const int ix = a_ix0[j] + (STEM ? lcol : kw * p.dil);                                                  \
+      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                          \
+      const float *src = in + a_base[j] + (iy * p.W + ix) * p.Cin + (STEM ? 0 : c0 + 4 * lcol);              \
+      ra[j] = ok ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);                 \
+    }                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < BPASS; ++j) {                                                      \
+      int row = lrow + j * RPP;                                                                              \
+      if (row >= BN) row = BN - 1; /* harmless duplicate load; the LDS store is guarded */                   \
+      rb[j] = *reinterpret_cast<const float4 *>(w + ((size_t)tap * p.Cout + n0 + row) * Kc + c0 + 4 * lcol); \
+    }                                                                                                        \
+  }
+#define UOC_LSTORE(STAGE)                                                                  \
+  {                                                                                        \
+    float *As_ = smem + (STAGE) * (BM + BN) * BKP;                                         \
+    float *Ws_ = As_ + BM * BKP;                                                           \
+    _Pragma("unroll") for (int j = 0; j < APASS; ++j) {                                    \
+      const int row = lrow + j * RPP;                                                      \
+      if (row < BM) *reinterpret_cast<float4 *>(As_ + row * BKP + 4 * lcol) = ra[j];       \
+    }                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < BPASS; ++j) {                                    \
+      const int row = lrow + j * RPP;                                                      \
+      if (row < BN) *reinterpret_cast<float4 *>(Ws_ + row * BKP + 4 * lcol) = rb[j];       \
+    }                                                                                      \
+  }
+#define UOC_FRAG(STAGE, HH, WA, XB)                                                                              \
+  {                                                                                                              \
+    const float *As_ = smem + (STAGE) * (BM + BN) * BKP;                                                         \
+    const float *Ws_ = As_ + BM * BKP;                                                                           \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) WA[j] =                                                       \
+        *reinterpret_cast<const float4 *>(Ws_ + (wn * WN + 16 * j + t) * BKP + 16 * (HH) + 4 * q);               \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) XB[i] =                                                       \
+        *reinterpret_cast<const float4 *>(As_ + (wm * WM + 16 * i + t) * BKP + 16 * (HH) + 4 * q);               \
+  }
+#define UOC_MFMA(WA, XB)                                                                                         \
+  {                                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[j][i] =    \
+        mfma4c(WA[j].x, XB[i].x, acc[j][i]);                                                                     \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[j][i] =    \
+        mfma4c(WA[j].y, XB[i].y, acc[j][i]);                                                                     \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[j][i] =    \
+        mfma4c(WA[j].z, XB[i].z, acc[j][i]);                                                                     \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[j][i] =    \
+        mfma4c(WA[j].w, XB[i].w, acc[j][i]);                                                                     \
+  }
+
   f32x4 acc[TN][TM];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // kc = -1 is the prologue (stage chunk 0 only); afterwards: global loads of chunk kc+1 fly under
-  // the MFMAs of chunk kc, are written to the other LDS stage, one barrier per chunk.
-  float4 ra[APASS], rb[BPASS];
-#pragma unroll
-  for (int j = 0; j < APASS; ++j) ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int j = 0; j < BPASS; ++j) rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int kc = -1; kc < nk; ++kc) {
+  float4 wa0[TN], xb0[TM], wa1[TN], xb1[TM];
+  UOC_GLOAD(0)
+  UOC_LSTORE(0)
+  __syncthreads();
+  UOC_FRAG(0, 0, wa0, xb0)
+  for (int kc = 0; kc < nk; ++kc) {
+    const int stage = kc & 1;
     const bool more = kc + 1 < nk;
-    if (more) {
-      const int kn = kc + 1;
-      const int tap = kn / cpt;
-      const int c0 = (kn - tap * cpt) * BK;
-      const int kh = STEM ? tap : tap / p.KW;
-      const int kw = STEM ? 0 : tap - kh * p.KW;
-#pragma unroll
-      for (int j = 0; j < APASS; ++j) {
-        const int iy = a_iy0[j] + kh * p.dil;
-        const int ix = a_ix0[j] + (STEM ? lcol : kw * p.dil);
-        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const float *src = in + a_base[j] + (iy * p.W + ix) * p.Cin + (STEM ? 0 : c0 + 4 * lcol);
-        ra[j] = ok ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int j = 0; j < BPASS; ++j) {
-        int row = lrow + j * RPP;
-        if (row >= BN) row = BN - 1;  // harmless duplicate load; the LDS store is guarded
-        rb[j] = *reinterpret_cast<const float4 *>(w + ((size_t)tap * p.Cout + n0 + row) * Kc + c0 + 4 * lcol);
-      }
-    }
-    if (kc >= 0) {
-      const float *As = smem + (kc & 1) * (BM + BN) * BKP;
-      const float *Ws = As + BM * BKP;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float4 wa[TN], xb[TM];
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          wa[j] = *reinterpret_cast<const float4 *>(Ws + (wn * WN + 16 * j + t) * BKP + 16 * h + 4 * q);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-          xb[i] = *reinterpret_cast<const float4 *>(As + (wm * WM + 16 * i + t) * BKP + 16 * h + 4 * q);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) acc[j][i] = mfma4c(wa[j].x, xb[i].x, acc[j][i]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) acc[j][i] = mfma4c(wa[j].y, xb[i].y, acc[j][i]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) acc[j][i] = mfma4c(wa[j].z, xb[i].z, acc[j][i]);
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int i = 0; i < TM; ++i) acc[j][i] = mfma4c(wa[j].w, xb[i].w, acc[j][i]);
-      }
-    }
-    if (more) {
-      float *As = smem + ((kc + 1) & 1) * (BM + BN) * BKP;
-      float *Ws = As + BM * BKP;
-#pragma unroll
-      for (int j = 0; j < APASS; ++j) {
-        const int row = lrow + j * RPP;
-        if (row < BM) *reinterpret_cast<float4 *>(As + row * BKP + 4 * lcol) = ra[j];
-      }
-#pragma unroll
-      for (int j = 0; j < BPASS; ++j) {
-        const int row = lrow + j * RPP;
-        if (row < BN) *reinterpret_cast<float4 *>(Ws + row * BKP + 4 * lcol) = rb[j];
-      }
-    }
+    if (more) UOC_GLOAD(kc + 1)
+    UOC_FRAG(stage, 1, wa1, xb1)
+    UOC_MFMA(wa0, xb0)
+    if (more) UOC_LSTORE(stage ^ 1)
     __syncthreads();
+    if (more) UOC_FRAG(stage ^ 1, 0, wa0, xb0)
+    UOC_MFMA(wa1, xb1)
   }
+#undef UOC_GLOAD
+#undef UOC_LSTORE
+#undef UOC_FRAG
+#undef UOC_MFMA
 
   // ---- epilogue: + folded-BN shift, + residual, ReLU; lane holds 4 consecutive couts of a pixel
 #pragma unroll

@@ -23,7 +23,7 @@ constexpr int FPS_THREADS = 256;
 constexpr int FPS_MAX_BLOCKS = 1024;
 constexpr int HC_THREADS = 256;
 constexpr int HC_MAX_BLOCKS = 1024;
-constexpr int ZP = 68;  // LDS row pitch (floats) of the seed tile: 4-dword skew per row
+constexpr int ZP = 72;  // LDS row pitch (floats) of the seed tile: 18 x 16 B => conflict-free b128 fragment reads
 constexpr int NLAB = UOC_MAX_SEEDS;
 
 struct ArgMax {

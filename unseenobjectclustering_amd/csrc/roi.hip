@@ -162,14 +162,14 @@ __global__ __launch_bounds__(256) void crop_stats_kernel(const int *__restrict__
 
 // keep[k][c] = cluster c of ROI k overlaps its stage-1 mask by >= 50 %; mean z of kept pixels
 // with z > 0 (all pixels if nothing is kept) (:129-136).  One block per ROI.
-__global__ __launch_bounds__(256) void crop_meanz_kernel(const int *__restrict__ labels_crop,
-                                                         const float *__restrict__ xyz_crop, int SS,
-                                                         const int *__restrict__ cnt, const int *__restrict__ ov,
-                                                         int *__restrict__ keep, float *__restrict__ meanz) {
+__global__ __launch_bounds__(1024) void crop_meanz_kernel(const int *__restrict__ labels_crop,
+                                                          const float *__restrict__ xyz_crop, int SS,
+                                                          const int *__restrict__ cnt, const int *__restrict__ ov,
+                                                          int *__restrict__ keep, float *__restrict__ meanz) {
   __shared__ int sk[NL];
   __shared__ int s_any;
-  __shared__ double rs[256];
-  __shared__ int rc[256];
+  __shared__ double rs[1024 / 64];
+  __shared__ int rc[1024 / 64];
   const int k = blockIdx.x;
   if (threadIdx.x == 0) s_any = 0;
   __syncthreads();
@@ -183,10 +183,11 @@ __global__ __launch_bounds__(256) void crop_meanz_kernel(const int *__restrict__
   __syncthreads();
   const int any = s_any;
   const float *z = xyz_crop + ((size_t)k * 3 + 2) * SS;
+  const int *lab = labels_crop + (size_t)k * SS;
   double sum = 0.0;
   int n = 0;
   for (int i = threadIdx.x; i < SS; i += blockDim.x) {
-    const int l = labels_crop[(size_t)k * SS + i];
+    const int l = lab[i];
     const bool sel = any ? ((unsigned)l < (unsigned)NL && sk[l]) : true;
     const float v = z[i];
     if (sel && v > 0.f) {
@@ -194,17 +195,25 @@ __global__ __launch_bounds__(256) void crop_meanz_kernel(const int *__restrict__
       ++n;
     }
   }
-  rs[threadIdx.x] = sum;
-  rc[threadIdx.x] = n;
-  __syncthreads();
-  for (int off = 128; off >= 1; off >>= 1) {
-    if (threadIdx.x < off) {
-      rs[threadIdx.x] += rs[threadIdx.x + off];
-      rc[threadIdx.x] += rc[threadIdx.x + off];
-    }
-    __syncthreads();
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    sum += __shfl_xor(sum, off);
+    n += __shfl_xor(n, off);
   }
-  if (threadIdx.x == 0) meanz[k] = (float)(rs[0] / (double)rc[0]);  // 0/0 -> NaN like torch.mean of an empty tensor
+  if ((threadIdx.x & 63) == 0) {
+    rs[threadIdx.x >> 6] = sum;
+    rc[threadIdx.x >> 6] = n;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s2 = 0.0;
+    int n2 = 0;
+    for (int w = 0; w < 1024 / 64; ++w) {
+      s2 += rs[w];
+      n2 += rc[w];
+    }
+    meanz[k] = (float)(s2 / (double)n2);  // 0/0 -> NaN like torch.mean of an empty tensor
+  }
 }
 
 // refined[p] = relabelled crop cluster of the LAST ROI (in paint order) covering p with a kept
@@ -335,7 +344,7 @@ int uoc_roi_match_stats(const int32_t *d_labels_crop, const float *d_mask_crops,
   int gb = (S * S + 255) / 256;
   if (gb > 64) gb = 64;
   hipLaunchKernelGGL(crop_stats_kernel, dim3(gb, K), dim3(256), 0, st, d_labels_crop, d_mask_crops, S * S, w.cnt, w.ov);
-  hipLaunchKernelGGL(crop_meanz_kernel, dim3(K), dim3(256), 0, st, d_labels_crop, d_xyz_crops, S * S, w.cnt, w.ov,
+  hipLaunchKernelGGL(crop_meanz_kernel, dim3(K), dim3(1024), 0, st, d_labels_crop, d_xyz_crops, S * S, w.cnt, w.ov,
                      d_keep, d_meanz);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
