@@ -93,10 +93,11 @@ size_t uoc_net_workspace_bytes(const uoc_net *net, int B, int H, int W);
 int uoc_net_forward(uoc_net *net, const float *d_rgb, const float *d_xyz, int B, int H, int W, float *d_embed,
                     void *d_ws, size_t ws_bytes, void *stream);
 
-/* Single fused conv (+bias +residual +ReLU), NHWC, weights [K*K][Cout][Cin]; K in {1,3}.
- * Cin % 32 == 0, Cout % 64 == 0.  Exposed for unit tests of the conv kernel. */
+/* Single fused conv (+bias +residual +ReLU), NHWC, over G independent groups stacked on the leading
+ * dimension (in [G][B][H][W][Cin], weights [G][K*K][Cout][Cin], bias [G][Cout], ...); K in {1,3}.
+ * Cin % 32 == 0, Cout % 64 == 0.  Exposed for unit tests / micro-benchmarks of the conv kernel. */
 int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, const float *d_res, float *d_out,
-                    int B, int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu,
+                    int G, int B, int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu,
                     void *stream);
 
 

@@ -55,7 +55,7 @@ def test_conv_kernel_vs_torch_cpu(device, case):
     out = torch.empty((B, Ho, Wo, Cout), device=device)
     L = _native.lib()
     rc = L.uoc_conv2d_nhwc(_native.ptr(xd), _native.ptr(wd), _native.ptr(bd), _native.ptr(rd), _native.ptr(out),
-                           B, H, W, Cin, Cout, K, stride, dil, pad, int(relu), _native.stream_ptr(device))
+                           1, B, H, W, Cin, Cout, K, stride, dil, pad, int(relu), _native.stream_ptr(device))
     _native.check(rc, "uoc_conv2d_nhwc")
     got = out.cpu().permute(0, 3, 1, 2)
     err = (got - ref).abs().max().item()

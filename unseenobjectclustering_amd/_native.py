@@ -33,7 +33,7 @@ def _declare(lib):
     lib.uoc_net_workspace_bytes.restype = c_size_t
     lib.uoc_net_workspace_bytes.argtypes = [P, c_int, c_int, c_int]
     lib.uoc_net_forward.argtypes = [P, P, P, c_int, c_int, c_int, P, P, c_size_t, P]
-    lib.uoc_conv2d_nhwc.argtypes = [P, P, P, P, P] + [c_int] * 10 + [P]
+    lib.uoc_conv2d_nhwc.argtypes = [P, P, P, P, P] + [c_int] * 11 + [P]
     for name in ("uoc_net_create", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_forward",
                  "uoc_conv2d_nhwc"):
         getattr(lib, name).restype = c_int

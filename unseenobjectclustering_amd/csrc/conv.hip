@@ -29,8 +29,8 @@ __device__ __forceinline__ f32x4 mfma4c(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
-__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvParams p, int ntiles) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, int VARIANT = 0>
+__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvParams p, int ntiles, int mtiles) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
@@ -40,8 +40,16 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvPa
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
-  const int g = blockIdx.y;
-  const int nt = blockIdx.x % ntiles, mt = blockIdx.x / ntiles;
+  // XCD-aware work mapping: hardware places block b on XCD b % 8 (speed only, never correctness).
+  // Work items are ordered (group, n-tile, m-tile) and each XCD takes a CONTIGUOUS slice, so the
+  // blocks sharing one [BN x K] weight slab sit behind the same 4 MiB L2.
+  const int total = p.G * ntiles * mtiles;
+  const int per_xcd = (total + 7) >> 3;
+  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (work >= total) return;
+  const int g = work / (ntiles * mtiles);
+  const int rem = work - g * (ntiles * mtiles);
+  const int nt = rem / mtiles, mt = rem - nt * mtiles;
   const int m0 = mt * BM, n0 = nt * BN;
   const int HoWo = p.Ho * p.Wo;
   const int M = p.B * HoWo;
@@ -93,8 +101,9 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvPa
 
 #define UOC_GLOAD(KN)                                                                                        \
   {                                                                                                          \
-    const int tap = (KN) / cpt;                                                                              \
-    const int c0 = ((KN)-tap * cpt) * BK;                                                                    \
+    const int cc_ = STEM ? 0 : (KN) / T; /* K order: cin slice outer, tap inner (L2 reuse of the slice) */ \
+    const int tap = (KN)-cc_ * T;                                                                            \
+    const int c0 = cc_ * BK;                                                                                 \
     const int kh = STEM ? tap : tap / p.KW;                                                                  \
     const int kw = STEM ? 0 : tap - kh * p.KW;                                                               \
     _Pragma("unroll") for (int j = 0; j < APASS; ++j) {                                                      \
@@ -155,15 +164,20 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvPa
   UOC_LSTORE(0)
   __syncthreads();
   UOC_FRAG(0, 0, wa0, xb0)
+  if (VARIANT >= 3) UOC_FRAG(0, 1, wa1, xb1)
   for (int kc = 0; kc < nk; ++kc) {
     const int stage = kc & 1;
     const bool more = kc + 1 < nk;
-    if (more) UOC_GLOAD(kc + 1)
-    UOC_FRAG(stage, 1, wa1, xb1)
+    // VARIANT != 0 are timing ablations only (wrong results): 1 = no global loads, 2 = also no LDS
+    // stores / barrier, 3 = also no fragment reads (pure MFMA issue rate).
+    if (more && VARIANT < 1) UOC_GLOAD(kc + 1)
+    if (VARIANT < 3) UOC_FRAG(stage, 1, wa1, xb1)
     UOC_MFMA(wa0, xb0)
-    if (more) UOC_LSTORE(stage ^ 1)
-    __syncthreads();
-    if (more) UOC_FRAG(stage ^ 1, 0, wa0, xb0)
+    if (VARIANT < 2) {
+      if (more) UOC_LSTORE(stage ^ 1)
+      __syncthreads();
+    }
+    if (more && VARIANT < 3) UOC_FRAG(stage ^ 1, 0, wa0, xb0)
     UOC_MFMA(wa1, xb1)
   }
 #undef UOC_GLOAD
@@ -200,6 +214,246 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvPa
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// Production variant: operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging,
+// no ds_write pass) into a 3-stage ring, two K-chunks ahead of the MFMAs, with counted vmcnt waits
+// and one raw s_barrier per chunk.  The LDS image of a DMA is lane-linear (8 lanes x 16 B = one
+// 128-byte row, no padding possible), so bank conflicts are removed by an XOR swizzle applied on
+// the SOURCE address and again on the fragment read: physical 16-B slot s of row r holds logical
+// slot s ^ ((r >> 1) & 7).  Out-of-image taps read a 128-byte zero page instead of being predicated.
+// Measured on the layer4 shape (ablation): register staging cost 14 % (global-load
+// wait) + 8 % (ds_write + barrier); this variant removes both.
+// -------------------------------------------------------------------------------------------
+__device__ float4 g_zero_page[8];  // zero-initialised device memory
+
+// One LDS-DMA: 64 lanes x 16 B land at LDS byte address `lds_dst` (wave-uniform) + 16*lane.  Written
+// as inline asm so that hipcc does not count it: with the builtin, the compiler drains the DMA queue
+// (s_waitcnt vmcnt(0)) in front of every ds_read; here the counted waits below are the only ones.
+// M0 carries the LDS base and is compiler-reserved, hence saved/restored inside the statement.
+__device__ __forceinline__ void glds16(const float *g, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(lds_dst)
+      : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
+__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvParams p, int ntiles, int mtiles) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int R = BM + BN;   // rows per stage (activation rows, then weight rows), 32 floats each
+  constexpr int RPP = NT / 8;  // rows per DMA pass: every wave moves 8 rows (1 KiB) per instruction
+  constexpr int NPASS = (R + RPP - 1) / RPP;
+  constexpr int STAGE = R * BK;  // floats per stage
+  static_assert(WM % 16 == 0 && WN % 16 == 0 && R % 8 == 0, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][R][32]
+
+  const int total = p.G * ntiles * mtiles;
+  const int per_xcd = (total + 7) >> 3;
+  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (work >= total) return;
+  const int g = work / (ntiles * mtiles);
+  const int rem = work - g * (ntiles * mtiles);
+  const int nt = rem / mtiles, mt = rem - nt * mtiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int HoWo = p.Ho * p.Wo;
+  const int M = p.B * HoWo;
+  const int Kc = STEM ? 32 : p.Cin;
+  const int T = STEM ? p.KH : p.KH * p.KW;
+  const int cpt = STEM ? 1 : p.Cin / BK;
+  const int nk = T * cpt;
+
+  const float *__restrict__ in = p.in + (size_t)g * p.B * p.H * p.W * p.Cin;
+  const float *__restrict__ w = p.w + (size_t)g * T * p.Cout * Kc;
+  const float *__restrict__ bias = p.bias + (size_t)g * p.Cout;
+  const float *__restrict__ res = p.res ? p.res + (size_t)g * M * p.Cout : nullptr;
+  float *__restrict__ out = p.out + (size_t)g * M * p.Cout;
+  const float *zero = reinterpret_cast<const float *>(g_zero_page);
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char *)smem);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int t = lane & 15, q = lane >> 4;
+
+  // ---- per-pass DMA descriptors (row r of the stage, physical slot s, logical slot c) -----------
+  int d_r0[NPASS];   // first row of this wave's 8-row group (wave-uniform)
+  int d_off[NPASS];  // A row: image base (+4c unless STEM) ; W row: (n0+n)*Kc + 4c
+  int d_iy0[NPASS], d_ix0[NPASS];
+  bool d_w[NPASS];
+#pragma unroll
+  for (int j = 0; j < NPASS; ++j) {
+    int r0 = j * RPP + wave * 8;
+    if (r0 >= R) r0 = R - 8;  // surplus wave: re-copy the last group (identical bytes) so every wave issues NPASS DMAs
+    d_r0[j] = r0;
+    const int r = r0 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    d_w[j] = r >= BM;
+    d_iy0[j] = -(1 << 28);
+    d_ix0[j] = 0;
+    if (r >= BM) {
+      d_off[j] = (n0 + (r - BM)) * Kc + 4 * c;
+    } else {
+      const int m = m0 + r;
+      d_off[j] = 0;
+      if (m < M) {
+        const int b = m / HoWo;
+        const int rr = m - b * HoWo;
+        const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+        d_iy0[j] = oy * p.stride - p.pad;
+        d_ix0[j] = ox * p.stride - p.pad + (STEM ? c : 0);
+        d_off[j] = b * p.H * p.W * p.Cin + (STEM ? 0 : 4 * c);
+      }
+    }
+  }
+
+#define UOC_ISSUE_ONE(KN, STG, J)                                                                              \
+  if ((J) < NPASS) {                                                                                           \
+    const int j = (J) < NPASS ? (J) : 0;                                                                       \
+    const int cc_ = STEM ? 0 : (KN) / T; /* K order: cin slice outer, tap inner (L2 reuse of the slice) */   \
+    const int tap = (KN)-cc_ * T;                                                                              \
+    const int c0 = cc_ * BK;                                                                                   \
+    const int kh = STEM ? tap : tap / p.KW;                                                                    \
+    const int kw = STEM ? 0 : tap - kh * p.KW;                                                                 \
+    const size_t woff = (size_t)tap * p.Cout * Kc + c0;                                                        \
+    const int iy = d_iy0[j] + kh * p.dil;                                                                      \
+    const int ix = d_ix0[j] + kw * p.dil;                                                                      \
+    const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                              \
+    /* branch-free source select: weight row | in-image activation row | zero page */                          \
+    const unsigned long long aw = (unsigned long long)(w + woff + d_off[j]);                                   \
+    const unsigned long long aa =                                                                              \
+        (unsigned long long)(in + d_off[j] + (iy * p.W + ix) * p.Cin + (STEM ? 0 : c0));                       \
+    const unsigned long long src = d_w[j] ? aw : (ok ? aa : (unsigned long long)zero);                         \
+    glds16(reinterpret_cast<const float *>(src),                                                               \
+           lds_base + (unsigned)(((STG)*STAGE + d_r0[j] * BK) * sizeof(float)));                               \
+  }
+#define UOC_ISSUE(KN, STG)                                                                                     \
+  {                                                                                                            \
+    UOC_ISSUE_ONE(KN, STG, 0) UOC_ISSUE_ONE(KN, STG, 1) UOC_ISSUE_ONE(KN, STG, 2) UOC_ISSUE_ONE(KN, STG, 3)    \
+    UOC_ISSUE_ONE(KN, STG, 4) UOC_ISSUE_ONE(KN, STG, 5)                                                        \
+  }
+#define UOC_FRAG2(STG, HH, WA, XB)                                                                           \
+  {                                                                                                          \
+    const float *base_ = smem + (STG)*STAGE;                                                                 \
+    const int slot_ = ((4 * (HH) + q) ^ ((t >> 1) & 7)) * 4;                                                 \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) WA[j] =                                                   \
+        *reinterpret_cast<const float4 *>(base_ + (BM + wn * WN + 16 * j + t) * BK + slot_);                 \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) XB[i] =                                                   \
+        *reinterpret_cast<const float4 *>(base_ + (wm * WM + 16 * i + t) * BK + slot_);                      \
+  }
+#define UOC_MFMA_E(WA, XB, E)                                                                                  \
+  {                                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[j][i] =  \
+        mfma4c(WA[j].E, XB[i].E, acc[j][i]);                                                                   \
+  }
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float4 wa0[TN], xb0[TM], wa1[TN], xb1[TM];
+  UOC_ISSUE(0, 0)
+  if (nk > 1) {
+    UOC_ISSUE(1, 1)
+    wait_vmcnt<NPASS>();
+  } else {
+    wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  UOC_FRAG2(0, 0, wa0, xb0)
+  int s_cur = 0, s_nxt = 1, s_nn = 2;  // ring positions of chunks kc, kc+1, kc+2
+  static_assert(NPASS <= 6, "DMA passes per chunk");
+  for (int kc = 0; kc < nk; ++kc) {
+    // (Spreading the DMAs between the MFMA groups was measured 5-15 % SLOWER than this burst.)
+    if (kc + 2 < nk) UOC_ISSUE(kc + 2, s_nn)
+    UOC_FRAG2(s_cur, 1, wa1, xb1)
+    UOC_MFMA_E(wa0, xb0, x)
+    UOC_MFMA_E(wa0, xb0, y)
+    UOC_MFMA_E(wa0, xb0, z)
+    UOC_MFMA_E(wa0, xb0, w)
+    if (kc + 2 < nk)
+      wait_vmcnt<NPASS>();  // chunk kc+1 has landed; chunk kc+2 may still be in flight
+    else
+      wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kc + 1 < nk) UOC_FRAG2(s_nxt, 0, wa0, xb0)
+    UOC_MFMA_E(wa1, xb1, x)
+    UOC_MFMA_E(wa1, xb1, y)
+    UOC_MFMA_E(wa1, xb1, z)
+    UOC_MFMA_E(wa1, xb1, w)
+    const int tmp = s_cur;
+    s_cur = s_nxt;
+    s_nxt = s_nn;
+    s_nn = tmp;
+  }
+#undef UOC_ISSUE
+#undef UOC_ISSUE_ONE
+#undef UOC_FRAG2
+#undef UOC_MFMA_E
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int co = n0 + wn * WN + 16 * j + 4 * q;
+    const float4 bv = *reinterpret_cast<const float4 *>(bias + co);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WM + 16 * i + t;
+      if (m < M) {
+        float4 v = make_float4(acc[j][i][0] + bv.x, acc[j][i][1] + bv.y, acc[j][i][2] + bv.z, acc[j][i][3] + bv.w);
+        if (res) {
+          const float4 rv = *reinterpret_cast<const float4 *>(res + (size_t)m * p.Cout + co);
+          v.x += rv.x;
+          v.y += rv.y;
+          v.z += rv.z;
+          v.w += rv.w;
+        }
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f);
+          v.y = fmaxf(v.y, 0.f);
+          v.z = fmaxf(v.z, 0.f);
+          v.w = fmaxf(v.w, 0.f);
+        }
+        *reinterpret_cast<float4 *>(out + (size_t)m * p.Cout + co) = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
+static int launch_glds(const ConvParams &p, hipStream_t st, int kc) {
+  const int M = p.B * p.Ho * p.Wo;
+  const double taps = (double)p.KH * p.KW;
+  const double flops = 2.0 * M * p.Cout * (STEM ? 3.0 : (double)p.Cin) * taps * p.G;
+  const double bytes = 4.0 * p.G * ((double)p.B * p.H * p.W * (STEM ? 3 : p.Cin) + taps * p.Cout * (STEM ? 3 : p.Cin) +
+                                    (double)M * p.Cout * (p.res ? 2 : 1));
+  ProfScope prof(kc, st, flops, bytes);
+  const int mtiles = (M + BM - 1) / BM, ntiles = p.Cout / BN;
+  const size_t lds = (size_t)3 * (BM + BN) * BK * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_kernel<BM, BN, WAVES_M, WAVES_N, STEM>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int total = mtiles * ntiles * p.G;
+  hipLaunchKernelGGL((conv_glds_kernel<BM, BN, WAVES_M, WAVES_N, STEM>), dim3(((total + 7) / 8) * 8),
+                     dim3(WAVES_M * WAVES_N * 64), lds, st, p, ntiles, mtiles);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
 // ---- tile configurations ---------------------------------------------------------------
 struct TileCfg {
   int BM, BN, threads;
@@ -214,7 +468,7 @@ static const TileCfg kCfgs[] = {
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kNumCU = 256;
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, int VARIANT = 0>
 static int launch_cfg(const ConvParams &p, hipStream_t st, int kc) {
   const int M = p.B * p.Ho * p.Wo;
   const double taps = (double)p.KH * p.KW;
@@ -226,12 +480,13 @@ static int launch_cfg(const ConvParams &p, hipStream_t st, int kc) {
   const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, STEM>),
+    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, STEM, VARIANT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, STEM>), dim3(mtiles * ntiles, p.G),
-                     dim3(WAVES_M * WAVES_N * 64), lds, st, p, ntiles);
+  const int total = mtiles * ntiles * p.G;
+  hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, STEM, VARIANT>), dim3(((total + 7) / 8) * 8),
+                     dim3(WAVES_M * WAVES_N * 64), lds, st, p, ntiles, mtiles);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
 }
@@ -259,26 +514,148 @@ static int pick_cfg(const ConvParams &p) {
   return best;
 }
 
+// ---- per-shape choice of (tile configuration, staging variant) --------------------------------
+// All candidates accumulate every output element in the same K order, so they are bit-identical;
+// the choice is purely a speed matter.  First use of a layer shape times the valid candidates
+// (3 launches each, HIP events) and caches the winner; a shape that differs only in batch size
+// (stage 2: one crop per ROI) reuses the nearest tuned neighbour instead of re-tuning.
+// UOC_CONV_AUTOTUNE=0 falls back to the static cost model; UOC_CONV_CFG / UOC_CONV_GLDS pin a choice.
+struct Choice {
+  int cfg;
+  int glds;
+};
+
+static int launch_choice(const ConvParams &p, hipStream_t st, Choice c) {
+  if (c.glds) {
+    switch (c.cfg) {
+      case 0: return launch_glds<160, 128, 2, 4, false>(p, st, KC_CONV_160x128);
+      case 1: return launch_glds<80, 128, 1, 8, false>(p, st, KC_CONV_80x128);
+      case 2: return launch_glds<160, 64, 2, 4, false>(p, st, KC_CONV_160x64);
+      case 3: return launch_glds<80, 64, 1, 4, false>(p, st, KC_CONV_80x64);
+    }
+  } else {
+    switch (c.cfg) {
+      case 0: return launch_cfg<160, 128, 2, 4, false>(p, st, KC_CONV_160x128);
+      case 1: return launch_cfg<80, 128, 1, 8, false>(p, st, KC_CONV_80x128);
+      case 2: return launch_cfg<160, 64, 2, 4, false>(p, st, KC_CONV_160x64);
+      case 3: return launch_cfg<80, 64, 1, 4, false>(p, st, KC_CONV_80x64);
+    }
+  }
+  set_error("conv: bad choice cfg=%d", c.cfg);
+  return UOC_EINVAL;
+}
+
+struct TuneKey {
+  int G, B, H, W, Cin, Cout, K, stride, dil;
+  bool same_layer(const TuneKey &o) const {
+    return G == o.G && H == o.H && W == o.W && Cin == o.Cin && Cout == o.Cout && K == o.K && stride == o.stride &&
+           dil == o.dil;
+  }
+};
+struct TuneEntry {
+  TuneKey key;
+  Choice choice;
+};
+static TuneEntry g_tuned[256];
+static int g_ntuned = 0;
+
+static Choice choose(const ConvParams &p, hipStream_t st, int glds_default) {
+  static int autotune = -1, pin_cfg = -2, pin_glds = -2;
+  if (autotune < 0) {
+    const char *e = getenv("UOC_CONV_AUTOTUNE");
+    autotune = e ? atoi(e) : 1;
+    e = getenv("UOC_CONV_CFG");
+    pin_cfg = e ? atoi(e) : -1;
+    e = getenv("UOC_CONV_GLDS");
+    pin_glds = e ? atoi(e) : -1;
+  }
+  Choice stat = {pick_cfg(p), pin_glds >= 0 ? pin_glds : glds_default};
+  if (!autotune || pin_cfg >= 0 || g_prof_enabled) {
+    if (!autotune || pin_cfg >= 0) return stat;
+  }
+  const TuneKey key = {p.G, p.B, p.H, p.W, p.Cin, p.Cout, p.KH, p.stride, p.dil};
+  int nearest = -1;
+  for (int i = 0; i < g_ntuned; ++i) {
+    if (!g_tuned[i].key.same_layer(key)) continue;
+    if (g_tuned[i].key.B == key.B) return g_tuned[i].choice;
+    if (nearest < 0 || abs(g_tuned[i].key.B - key.B) < abs(g_tuned[nearest].key.B - key.B)) nearest = i;
+  }
+  if (nearest >= 0) {
+    // same layer, other batch: reuse if the tile is still legal, never re-tune mid-stream
+    return g_tuned[nearest].choice;
+  }
+  if (g_ntuned >= 256) return stat;
+  const bool prof_was = g_prof_enabled;
+  g_prof_enabled = false;
+  hipEvent_t e0, e1;
+  Choice best = stat;
+  float best_ms = 1e30f;
+  if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+    for (int cfg = 0; cfg < kNumCfg; ++cfg) {
+      if (p.Cout % kCfgs[cfg].BN) continue;
+      for (int gl = 0; gl < 2; ++gl) {
+        if (pin_glds >= 0 && gl != pin_glds) continue;
+        const Choice c = {cfg, gl};
+        if (launch_choice(p, st, c) != UOC_OK) continue;  // warm-up (also sets the LDS attribute)
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < 3; ++r) (void)launch_choice(p, st, c);
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) {
+          best_ms = ms;
+          best = c;
+        }
+      }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  g_prof_enabled = prof_was;
+  g_tuned[g_ntuned].key = key;
+  g_tuned[g_ntuned].choice = best;
+  ++g_ntuned;
+  if (getenv("UOC_CONV_VERBOSE"))
+    fprintf(stderr, "[uoc] conv G%d B%d %dx%d %d->%d k%d s%d d%d : cfg %d glds %d (%.1f us)\n", p.G, p.B, p.H, p.W, p.Cin,
+            p.Cout, p.KH, p.stride, p.dil, best.cfg, best.glds, best_ms * 1e3f / 3);
+  return best;
+}
+
 int launch_conv(const ConvParams &p, hipStream_t st) {
   UOC_REQUIRE(p.in && p.w && p.bias && p.out, "conv: null pointer");
   UOC_REQUIRE(p.G >= 1 && p.B >= 1 && p.H >= 1 && p.W >= 1, "conv: bad shape");
   UOC_REQUIRE((long)p.B * p.H * p.W * p.Cin < (1l << 31) && (long)p.B * p.Ho * p.Wo * p.Cout < (1l << 31),
               "conv: tensor too large for 32-bit indexing");
+  static int use_glds = -1;
+  if (use_glds < 0) {
+    const char *e = getenv("UOC_CONV_GLDS");  // 0 = register-staged kernel (kept for A/B measurements)
+    use_glds = e ? atoi(e) : 1;
+  }
   if (p.stem) {
     UOC_REQUIRE(p.Cin == 4 && p.KH == 7 && p.KW == 7 && p.stride == 2 && p.pad == 3 && p.dil == 1 && p.Cout == 64,
                 "conv: stem path is 7x7 s2 p3, NHWC4 -> 64 only");
+    if (use_glds) return launch_glds<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
     return launch_cfg<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
   }
   UOC_REQUIRE(p.Cin % BK == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, BK);
   UOC_REQUIRE(p.Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", p.Cout);
-  switch (pick_cfg(p)) {
-    case 0: return launch_cfg<160, 128, 2, 4, false>(p, st, KC_CONV_160x128);
-    case 1: return launch_cfg<80, 128, 1, 8, false>(p, st, KC_CONV_80x128);
-    case 2: return launch_cfg<160, 64, 2, 4, false>(p, st, KC_CONV_160x64);
-    case 3: return launch_cfg<80, 64, 1, 4, false>(p, st, KC_CONV_80x64);
+  static int variant = -1;
+  if (variant < 0) {
+    const char *e = getenv("UOC_CONV_VARIANT");  // timing ablations of the 160x128 kernel (dev only)
+    variant = e ? atoi(e) : 0;
   }
-  set_error("conv: no tile configuration for Cout=%d", p.Cout);
-  return UOC_EINVAL;
+  if (variant > 0 && pick_cfg(p) == 0) {
+    if (variant == 1) return launch_cfg<160, 128, 2, 4, false, 1>(p, st, KC_CONV_160x128);
+    if (variant == 2) return launch_cfg<160, 128, 2, 4, false, 2>(p, st, KC_CONV_160x128);
+    return launch_cfg<160, 128, 2, 4, false, 3>(p, st, KC_CONV_160x128);
+  }
+  const Choice ch = choose(p, st, use_glds);
+  if (ch.cfg < 0) {
+    set_error("conv: no tile configuration for Cout=%d", p.Cout);
+    return UOC_EINVAL;
+  }
+  return launch_choice(p, st, ch);
 }
 
 // ---- NCHW(3) -> NHWC4 ------------------------------------------------------------------

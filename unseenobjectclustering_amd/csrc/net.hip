@@ -310,9 +310,11 @@ int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, i
   return launch_head(w.fc, w.fc + (size_t)B * h * wd * 64, d_embed, B, h, wd, H, W, st);
 }
 
-/* Generic NHWC convolution entry (unit tests / integration): weights [T][Cout][Cin] with BN folded. */
-int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, const float *d_res, float *d_out, int B,
-                    int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu, void *stream) {
+/* Generic NHWC convolution entry (unit tests / integration): G independent groups stacked on the
+ * leading dimension; per group: weights [T][Cout][Cin] with BN folded. */
+int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, const float *d_res, float *d_out, int G,
+                    int B, int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu,
+                    void *stream) {
   UOC_REQUIRE(K == 1 || K == 3, "K=%d (only 1 or 3)", K);
   ConvParams p;
   p.in = d_in;
@@ -320,7 +322,7 @@ int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, co
   p.bias = d_bias;
   p.res = d_res;
   p.out = d_out;
-  p.G = 1;
+  p.G = G;
   p.B = B;
   p.H = H;
   p.W = W;
