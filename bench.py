@@ -177,7 +177,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom["kernel"])
-        if dom["kernel"].startswith("conv") or dom["kernel"] in ("hc_iter", "assign"):
+        if dom["kernel"].startswith("conv") or dom["kernel"] in ("hc_iter", "assign"):   # MFMA-bound classes
             ach = dom["flops"] / sec / 1e12
             roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,

@@ -528,10 +528,10 @@ struct Choice {
 static int launch_choice(const ConvParams &p, hipStream_t st, Choice c) {
   if (c.glds) {
     switch (c.cfg) {
-      case 0: return launch_glds<160, 128, 2, 4, false>(p, st, KC_CONV_160x128);
-      case 1: return launch_glds<80, 128, 1, 8, false>(p, st, KC_CONV_80x128);
-      case 2: return launch_glds<160, 64, 2, 4, false>(p, st, KC_CONV_160x64);
-      case 3: return launch_glds<80, 64, 1, 4, false>(p, st, KC_CONV_80x64);
+      case 0: return launch_glds<160, 128, 2, 4, false>(p, st, KC_GLDS_160x128);
+      case 1: return launch_glds<80, 128, 1, 8, false>(p, st, KC_GLDS_80x128);
+      case 2: return launch_glds<160, 64, 2, 4, false>(p, st, KC_GLDS_160x64);
+      case 3: return launch_glds<80, 64, 1, 4, false>(p, st, KC_GLDS_80x64);
     }
   } else {
     switch (c.cfg) {
@@ -559,6 +559,31 @@ struct TuneEntry {
 static TuneEntry g_tuned[256];
 static int g_ntuned = 0;
 
+// Optional persistence (UOC_CONV_TUNE_CACHE=<file>): choices measured by one process are reused by
+// the next, e.g. so that a profiled run contains no tuning launches.
+static void tune_cache_load() {
+  const char *path = getenv("UOC_CONV_TUNE_CACHE");
+  if (!path) return;
+  FILE *f = fopen(path, "r");
+  if (!f) return;
+  TuneEntry e;
+  while (g_ntuned < 256 && fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d", &e.key.G, &e.key.B, &e.key.H, &e.key.W,
+                                  &e.key.Cin, &e.key.Cout, &e.key.K, &e.key.stride, &e.key.dil, &e.choice.cfg,
+                                  &e.choice.glds) == 11) {
+    if (e.choice.cfg >= 0 && e.choice.cfg < 4) g_tuned[g_ntuned++] = e;
+  }
+  fclose(f);
+}
+static void tune_cache_append(const TuneEntry &e) {
+  const char *path = getenv("UOC_CONV_TUNE_CACHE");
+  if (!path) return;
+  FILE *f = fopen(path, "a");
+  if (!f) return;
+  fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d\n", e.key.G, e.key.B, e.key.H, e.key.W, e.key.Cin, e.key.Cout, e.key.K,
+          e.key.stride, e.key.dil, e.choice.cfg, e.choice.glds);
+  fclose(f);
+}
+
 static Choice choose(const ConvParams &p, hipStream_t st, int glds_default) {
   static int autotune = -1, pin_cfg = -2, pin_glds = -2;
   if (autotune < 0) {
@@ -568,11 +593,10 @@ static Choice choose(const ConvParams &p, hipStream_t st, int glds_default) {
     pin_cfg = e ? atoi(e) : -1;
     e = getenv("UOC_CONV_GLDS");
     pin_glds = e ? atoi(e) : -1;
+    tune_cache_load();
   }
   Choice stat = {pick_cfg(p), pin_glds >= 0 ? pin_glds : glds_default};
-  if (!autotune || pin_cfg >= 0 || g_prof_enabled) {
-    if (!autotune || pin_cfg >= 0) return stat;
-  }
+  if (!autotune || pin_cfg >= 0) return stat;
   const TuneKey key = {p.G, p.B, p.H, p.W, p.Cin, p.Cout, p.KH, p.stride, p.dil};
   int nearest = -1;
   for (int i = 0; i < g_ntuned; ++i) {
@@ -615,6 +639,7 @@ static Choice choose(const ConvParams &p, hipStream_t st, int glds_default) {
   g_prof_enabled = prof_was;
   g_tuned[g_ntuned].key = key;
   g_tuned[g_ntuned].choice = best;
+  tune_cache_append(g_tuned[g_ntuned]);
   ++g_ntuned;
   if (getenv("UOC_CONV_VERBOSE"))
     fprintf(stderr, "[uoc] conv G%d B%d %dx%d %d->%d k%d s%d d%d : cfg %d glds %d (%.1f us)\n", p.G, p.B, p.H, p.W, p.Cin,

@@ -13,6 +13,10 @@ enum KernelClass {
   KC_CONV_160x64,
   KC_CONV_80x64,
   KC_CONV_STEM,
+  KC_GLDS_160x128,
+  KC_GLDS_80x128,
+  KC_GLDS_160x64,
+  KC_GLDS_80x64,
   KC_NET_MISC,  // layout conversion, max-pool
   KC_HEAD,
   KC_FPS_STEP,
