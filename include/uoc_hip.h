@@ -40,6 +40,10 @@ const char *uoc_last_error(void);
  * Mean-shift clustering  — replaces lib/utils/mean_shift.py:128-229 (cosine metric)
  * ---------------------------------------------------------------------------------------- */
 
+/* Seed selection runs as ONE persistent cooperative launch with X resident on chip when the batch
+ * fits the device (default); 0 forces the streaming one-launch-per-step kernel.  Same results. */
+int uoc_ms_set_persistent_fps(int on);
+
 /* Scratch bytes the clustering entry points need for (batch, n, m). */
 size_t uoc_ms_workspace_bytes(int batch, int n, int m);
 

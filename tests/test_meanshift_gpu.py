@@ -124,3 +124,23 @@ def test_degenerate_inputs(device):
     lo, io = O.mean_shift_smart_init(torch.from_numpy(v), KAPPA, 100, 10, first_index=7, epsilon=EPSILON)
     assert np.array_equal(idx[0].cpu().numpy(), io.numpy())
     assert np.array_equal(labels[0].cpu().numpy(), lo.numpy())
+
+
+@pytest.mark.parametrize("shape,batch", [((480, 640), 1), ((224, 224), 7), ((224, 224), 12), ((37, 53), 3)])
+def test_persistent_and_streaming_seed_selection_agree(device, shape, batch):
+    """The on-chip persistent farthest-point kernel and the one-launch-per-step kernel must pick the
+    same 100 indices (batch 12 x 224^2 does not fit on chip and exercises the automatic fallback)."""
+    from unseenobjectclustering_amd import _native
+    L = _native.lib()
+    H, W = shape
+    fields = [torch.from_numpy(synth.embedding_field(60 + k, H, W, 64, 3 + k % 4, 0.05)[0]) for k in range(batch)]
+    Xb = torch.stack(fields).to(device)
+    firsts = [(977 * k + 13) % (H * W) for k in range(batch)]
+    try:
+        L.uoc_ms_set_persistent_fps(1)
+        l1, i1 = MS.cluster_batch(Xb, firsts, KAPPA, 100, 10, EPSILON)
+        L.uoc_ms_set_persistent_fps(0)
+        l0, i0 = MS.cluster_batch(Xb, firsts, KAPPA, 100, 10, EPSILON)
+    finally:
+        L.uoc_ms_set_persistent_fps(1)
+    assert torch.equal(i1, i0) and torch.equal(l1, l0)

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
 #define UOC_ISSUE(KN, STG)                                                                                     \
   {                                                                                                            \
     UOC_ISSUE_ONE(KN, STG, 0) UOC_ISSUE_ONE(KN, STG, 1) UOC_ISSUE_ONE(KN, STG, 2) UOC_ISSUE_ONE(KN, STG, 3)    \
-    UOC_ISSUE_ONE(KN, STG, 4) UOC_ISSUE_ONE(KN, STG, 5)                                                        \
+    UOC_ISSUE_ONE(KN, STG, 4) UOC_ISSUE_ONE(KN, STG, 5) UOC_ISSUE_ONE(KN, STG, 6) UOC_ISSUE_ONE(KN, STG, 7)    \
   }
 #define UOC_FRAG2(STG, HH, WA, XB)                                                                           \
   {                                                                                                          \
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
   __builtin_amdgcn_s_barrier();
   UOC_FRAG2(0, 0, wa0, xb0)
   int s_cur = 0, s_nxt = 1, s_nn = 2;  // ring positions of chunks kc, kc+1, kc+2
-  static_assert(NPASS <= 6, "DMA passes per chunk");
+  static_assert(NPASS <= 8, "DMA passes per chunk");
   for (int kc = 0; kc < nk; ++kc) {
     // (Spreading the DMAs between the MFMA groups was measured 5-15 % SLOWER than this burst.)
     if (kc + 2 < nk) UOC_ISSUE(kc + 2, s_nn)
@@ -464,6 +464,7 @@ static const TileCfg kCfgs[] = {
     {80, 128, 512, 1.06f},   // 1: 1x8 waves, wave tile 80x16
     {160, 64, 512, 1.06f},   // 2: 2x4 waves, wave tile 80x16
     {80, 64, 256, 1.12f},    // 3: 1x4 waves, wave tile 80x16
+    {80, 128, 256, 1.03f},   // 4: 1x4 waves, wave tile 80x32 — two such blocks share a CU and de-synchronise
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kNumCU = 256;
@@ -532,6 +533,7 @@ static int launch_choice(const ConvParams &p, hipStream_t st, Choice c) {
       case 1: return launch_glds<80, 128, 1, 8, false>(p, st, KC_GLDS_80x128);
       case 2: return launch_glds<160, 64, 2, 4, false>(p, st, KC_GLDS_160x64);
       case 3: return launch_glds<80, 64, 1, 4, false>(p, st, KC_GLDS_80x64);
+      case 4: return launch_glds<80, 128, 1, 4, false>(p, st, KC_GLDS_80x128);
     }
   } else {
     switch (c.cfg) {
@@ -539,6 +541,7 @@ static int launch_choice(const ConvParams &p, hipStream_t st, Choice c) {
       case 1: return launch_cfg<80, 128, 1, 8, false>(p, st, KC_CONV_80x128);
       case 2: return launch_cfg<160, 64, 2, 4, false>(p, st, KC_CONV_160x64);
       case 3: return launch_cfg<80, 64, 1, 4, false>(p, st, KC_CONV_80x64);
+      case 4: return launch_cfg<80, 128, 1, 4, false>(p, st, KC_CONV_80x128);
     }
   }
   set_error("conv: bad choice cfg=%d", c.cfg);
@@ -570,7 +573,7 @@ static void tune_cache_load() {
   while (g_ntuned < 256 && fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d", &e.key.G, &e.key.B, &e.key.H, &e.key.W,
                                   &e.key.Cin, &e.key.Cout, &e.key.K, &e.key.stride, &e.key.dil, &e.choice.cfg,
                                   &e.choice.glds) == 11) {
-    if (e.choice.cfg >= 0 && e.choice.cfg < 4) g_tuned[g_ntuned++] = e;
+    if (e.choice.cfg >= 0 && e.choice.cfg < kNumCfg) g_tuned[g_ntuned++] = e;
   }
   fclose(f);
 }

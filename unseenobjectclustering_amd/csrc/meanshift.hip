@@ -15,6 +15,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stdlib.h>
 
 namespace uoc {
 
@@ -141,6 +142,163 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
 }
 
 // -------------------------------------------------------------------------------------------
+// Persistent farthest-point sampling: ONE launch for all m steps.  Every block keeps its share of
+// X resident on chip for the whole call — 36 pixel-slots per wave in VGPRs (4 pixels x 16 lanes x
+// float4 each) plus up to 18 in LDS, i.e. up to 1728 pixels per CU — so a step costs no HBM/L2 traffic at
+// all, only the dot products and a grid-wide argmax.  The argmax exchange is a tagged-granule
+// all-gather (MI355X_MICROARCH "R2": the 8-byte {value, index|tag} word written with ONE agent-scope
+// atomic store is its own flag; no fences, no counters): each block publishes its (max, lowest
+// index) for step s in slot [s&1][block], one wave per block sweeps the row until every tag equals
+// s+1.  Two slots suffice: a block can only be one step ahead of the slowest reader.
+// Placement independent; needs all blocks co-resident => launched cooperatively with
+// grid <= #CUs (512-thread blocks with a 256-register budget, one per CU); every spin is bounded and sets *status on expiry.
+// -------------------------------------------------------------------------------------------
+constexpr int FPP_THREADS = 512;
+constexpr int FPP_WAVES = FPP_THREADS / 64;
+constexpr int FPP_RS = 36;  // register slots per wave
+constexpr int FPP_LS = 18;  // LDS slots per wave
+constexpr int FPP_SLOTS = FPP_RS + FPP_LS;
+constexpr int FPP_PIX_PER_BLOCK = FPP_WAVES * FPP_SLOTS * 4;  // 1728
+
+__device__ __forceinline__ unsigned long long fpp_pack(float val, int idx, int tag) {
+  return ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)(idx & 0xFFFFFF) | ((unsigned)(tag & 0xFF) << 24);
+}
+
+__global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
+    const float *__restrict__ X, int n, int m, int bpi, int nslots, const int *__restrict__ first_index,
+    float *__restrict__ seeds, int *__restrict__ indices, unsigned long long *gran, int *status) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [FPP_WAVES][FPP_LS][64 lanes] float4
+  __shared__ ArgMax red[FPP_WAVES];
+  __shared__ int s_idx;
+  const int item = blockIdx.x / bpi, blk = blockIdx.x - item * bpi;
+  X += (size_t)item * n * C;
+  seeds += (size_t)item * m * C;
+  indices += (size_t)item * m;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 15, g = lane >> 4;
+  const int ppb = FPP_WAVES * nslots * 4;                    // pixels owned by one block
+  const int pbase = blk * ppb + wave * nslots * 4 + g;       // + 4*slot
+  float4 *lds = reinterpret_cast<float4 *>(smem) + (size_t)wave * FPP_LS * 64 + lane;
+  float *lds_dm = smem + (size_t)FPP_WAVES * FPP_LS * 64 * 4 + wave * FPP_LS * 4;  // [wave][slot][g]
+
+  // ---- load this wave's pixels once -----------------------------------------------------------
+  float4 x[FPP_RS];
+#pragma unroll
+  for (int i = 0; i < FPP_RS; ++i) {
+    const int p = pbase + 4 * i;
+    x[i] = (i < nslots && p < n) ? *reinterpret_cast<const float4 *>(X + (size_t)p * C + 4 * t)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int i = FPP_RS; i < nslots; ++i) {
+    const int p = pbase + 4 * i;
+    lds[(i - FPP_RS) * 64] = (p < n) ? *reinterpret_cast<const float4 *>(X + (size_t)p * C + 4 * t)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float dm[(FPP_RS + 15) / 16];
+#pragma unroll
+  for (int i = 0; i < (FPP_RS + 15) / 16; ++i) dm[i] = 0.f;  // running min distance of slot i lives in lane t == (i & 15), register i >> 4
+
+  int cur = first_index[item];
+  if (blk == 0) {
+    if (tid == 0) indices[0] = cur;
+    if (tid < 16) *reinterpret_cast<float4 *>(seeds + 4 * tid) = *reinterpret_cast<const float4 *>(X + (size_t)cur * C + 4 * tid);
+  }
+  for (int step = 0; step + 1 < m; ++step) {
+    const float4 sv = *reinterpret_cast<const float4 *>(X + (size_t)cur * C + 4 * t);
+    ArgMax best = {-INFINITY, INT_MAX};
+#define UOC_FPP_SLOT(I, XV)                                                      \
+  {                                                                              \
+    float s_ = (XV).x * sv.x;                                                    \
+    s_ = fmaf((XV).y, sv.y, s_);                                                 \
+    s_ = fmaf((XV).z, sv.z, s_);                                                 \
+    s_ = fmaf((XV).w, sv.w, s_);                                                 \
+    s_ = row16_sum(s_);                                                          \
+    if (t == ((I)&15)) {                                                         \
+      float d_ = 0.5f * (1.0f - s_);                                             \
+      if (step > 0) d_ = fminf(d_, dm[(I) >> 4]);                                \
+      dm[(I) >> 4] = d_;                                                         \
+      const int p_ = pbase + 4 * (I);                                            \
+      if (p_ < n && d_ > best.val) { /* slots ascend per lane: '>' keeps the lowest index */ \
+        best.val = d_;                                                           \
+        best.idx = p_;                                                           \
+      }                                                                          \
+    }                                                                            \
+  }
+#pragma unroll
+    for (int i = 0; i < FPP_RS; ++i)
+      if (i < nslots) UOC_FPP_SLOT(i, x[i])
+    // LDS-resident slots: rolled loop (keeps register pressure flat); their running minima live in LDS
+#pragma unroll 2
+    for (int i = FPP_RS; i < nslots; ++i) {
+      const float4 xv = lds[(i - FPP_RS) * 64];
+      float s_ = xv.x * sv.x;
+      s_ = fmaf(xv.y, sv.y, s_);
+      s_ = fmaf(xv.z, sv.z, s_);
+      s_ = fmaf(xv.w, sv.w, s_);
+      s_ = row16_sum(s_);
+      if (t == 0) {
+        float *dmp = lds_dm + (i - FPP_RS) * 4 + g;
+        float d_ = 0.5f * (1.0f - s_);
+        if (step > 0) d_ = fminf(d_, *dmp);
+        *dmp = d_;
+        const int p_ = pbase + 4 * i;
+        if (p_ < n && d_ > best.val) {
+          best.val = d_;
+          best.idx = p_;
+        }
+      }
+    }
+#undef UOC_FPP_SLOT
+    best = wave_argmax(best);
+    if (lane == 0) red[wave] = best;
+    __syncthreads();
+    if (wave == 0) {
+      ArgMax b2 = lane < FPP_WAVES ? red[lane] : ArgMax{-INFINITY, INT_MAX};
+      b2 = wave_argmax(b2);
+      unsigned long long *row = gran + ((size_t)(step & 1) * gridDim.x + (size_t)item * bpi);
+      const int tag = (step + 1) & 0xFF;
+      if (lane == 0) __hip_atomic_store(row + blk, fpp_pack(b2.val, b2.idx, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // sweep the item's row until every granule carries this step's tag
+      ArgMax acc = {-INFINITY, INT_MAX};
+      unsigned spins = 0;
+      bool done = false;
+      while (!done) {
+        bool ok = true;
+        ArgMax a = {-INFINITY, INT_MAX};
+        for (int k = lane; k < bpi; k += 64) {
+          const unsigned long long v = __hip_atomic_load(row + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok &= (int)((v >> 24) & 0xFF) == tag;
+          ArgMax c = {__uint_as_float((unsigned)(v >> 32)), (int)(v & 0xFFFFFF)};
+          if (better(c, a)) a = c;
+        }
+        if (__all(ok)) {
+          acc = a;
+          done = true;
+        } else {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 22) || (((spins & 1023) == 0) && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            if (lane == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc = ArgMax{0.f, 0};
+            done = true;
+          }
+        }
+      }
+      acc = wave_argmax(acc);
+      if (lane == 0) s_idx = acc.idx;
+    }
+    __syncthreads();
+    cur = s_idx;
+    if (cur < 0 || cur >= n) cur = 0;  // only reachable after a timeout
+    if (blk == 0) {
+      if (tid == 0) indices[step + 1] = cur;
+      if (tid < 16)
+        *reinterpret_cast<float4 *>(seeds + (size_t)(step + 1) * C + 4 * tid) =
+            *reinterpret_cast<const float4 *>(X + (size_t)cur * C + 4 * tid);
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
 // One hill-climbing iteration.  Each wave owns 16-pixel tiles and all ST seed tiles:
 //   S^T[pixel][seed] = X Z^T       16 x v_mfma_f32_16x16x4_f32 per (16 px x 16 seeds)
 //   W = exp(kappa S)               in registers: the D fragment of step 1 IS the A fragment of step 3
@@ -150,6 +308,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
 // exists in memory.  Wave partials are reduced through LDS; block partials go to HBM and are
 // reduced (fixed order) + L2-normalised by hc_finalize_kernel.
 // -------------------------------------------------------------------------------------------
+#ifndef UOC_EXP
+#define UOC_EXP expf
+#endif
+__device__ __forceinline__ float f4c(const float4 &v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -206,26 +368,30 @@ __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__rest
   for (; tile < ntile; tile += stride) {
     float4 na[4], nb[4];
     load_tile(tile + stride, na, nb);  // software prefetch of the wave's next tile
+    // Software pipeline over the seed tiles (3 stages, fully unrolled): in step i the 16-deep
+    // DEPENDENT MFMA chain S_i = X Z_i^T is interleaved 1:1 with the 16 INDEPENDENT accumulate MFMAs of
+    // tile i-2 (hides the 40-cycle dependent-accumulator latency), while exp() of tile i-1 runs on the
+    // VALU underneath.
+    f32x4 Sv[ST];
+    float wv[ST][4];
 #pragma unroll
-    for (int s = 0; s < ST; ++s) {
-      f32x4 S = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < ST + 2; ++i) {
+      if (i >= 1 && i - 1 < ST) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const float4 zb = *reinterpret_cast<const float4 *>(Zs + (16 * s + t) * ZP + 16 * v + 4 * q);
-        S = mfma4(xa[v].x, zb.x, S);
-        S = mfma4(xa[v].y, zb.y, S);
-        S = mfma4(xa[v].z, zb.z, S);
-        S = mfma4(xa[v].w, zb.w, S);
+        for (int r = 0; r < 4; ++r) wv[i - 1][r] = UOC_EXP(kappa * Sv[i - 1][r]);
       }
-      float w[4];
+      if (i < ST) Sv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) w[r] = expf(kappa * S[r]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        acc[s][0] = mfma4(w[r], xb[r].x, acc[s][0]);
-        acc[s][1] = mfma4(w[r], xb[r].y, acc[s][1]);
-        acc[s][2] = mfma4(w[r], xb[r].z, acc[s][2]);
-        acc[s][3] = mfma4(w[r], xb[r].w, acc[s][3]);
+      for (int k = 0; k < 16; ++k) {
+        if (i < ST) {
+          const int v = k >> 2, e = k & 3;
+          const float4 zb = *reinterpret_cast<const float4 *>(Zs + (16 * i + t) * ZP + 16 * v + 4 * q);
+          Sv[i] = mfma4(f4c(xa[v], e), f4c(zb, e), Sv[i]);
+        }
+        if (i >= 2) {
+          const int r = k >> 2, ct = k & 3;
+          acc[i - 2][ct] = mfma4(wv[i - 2][r], f4c(xb[r], ct), acc[i - 2][ct]);
+        }
       }
     }
 #pragma unroll
@@ -511,7 +677,15 @@ struct MsWorkspace {
 
 static int hc_blocks(int batch, int n) {
   const int ntile = (n + 15) / 16;
-  int nblk = 512 / (batch > 0 ? batch : 1);
+  // one 4-wave block per CU: the kernel runs 1 wave/SIMD (335 registers), so more blocks only add
+  // prologue (Z -> LDS) / epilogue (partial reduce + 28 KB store) work and partial traffic
+  static int target = 0;
+  if (!target) {
+    const char *e = getenv("UOC_HC_BLOCKS");
+    target = e ? atoi(e) : 256;
+    if (target < 1) target = 256;
+  }
+  int nblk = target / (batch > 0 ? batch : 1);
   if (nblk < 8) nblk = 8;
   const int maxb = (ntile + 3) / 4;
   if (nblk > maxb) nblk = maxb;
@@ -561,8 +735,60 @@ static int fps_blocks(int n) {
   return nblk;
 }
 
+static int g_num_cu = 0;
+static int g_fps_persistent = -1;  // -1: read UOC_FPS_PERSISTENT on first use
+static int fps_persistent_plan(int batch, int n, int *bpi, int *nslots) {
+  if (g_num_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    g_num_cu = prop.multiProcessorCount;
+  }
+  if (g_fps_persistent < 0) {
+    const char *e = getenv("UOC_FPS_PERSISTENT");
+    g_fps_persistent = e ? atoi(e) : 1;
+  }
+  if (!g_fps_persistent || n >= (1 << 24)) return 0;
+  int b = g_num_cu / batch;  // blocks per item: as many as stay co-resident
+  if (b < 1) return 0;
+  if (b > 256) b = 256;
+  const int per_block = (n + b - 1) / b;
+  int ns = (per_block + FPP_WAVES * 4 - 1) / (FPP_WAVES * 4);
+  if (ns > FPP_SLOTS) return 0;  // does not fit on chip: use the streaming kernel
+  if (ns < 1) ns = 1;
+  b = (n + FPP_WAVES * ns * 4 - 1) / (FPP_WAVES * ns * 4);  // drop blocks that would own no pixel
+  *bpi = b;
+  *nslots = ns;
+  return 1;
+}
+
 static int run_select_seeds(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
                             int32_t *indices, const MsWorkspace &w, hipStream_t st) {
+  int bpi = 0, nslots = 0;
+  if (m >= 2 && fps_persistent_plan(batch, n, &bpi, &nslots)) {
+    unsigned long long *gran = reinterpret_cast<unsigned long long *>(w.part[0]);
+    int *status = reinterpret_cast<int *>(w.part[1]);
+    const size_t gbytes = (size_t)2 * batch * bpi * sizeof(unsigned long long);
+    if (gbytes <= (size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax)) {
+      UOC_HIP_CHECK(hipMemsetAsync(gran, 0, gbytes, st));   // tag 0 = "not published": re-initialised every call
+      UOC_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int), st));
+      const size_t lds = (size_t)FPP_WAVES * FPP_LS * (64 * sizeof(float4) + 4 * sizeof(float));
+      static bool attr_set = false;
+      if (!attr_set) {
+        UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_persistent_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+      }
+      const float *Xc = X;
+      void *args[] = {(void *)&Xc, (void *)&n, (void *)&m, (void *)&bpi, (void *)&nslots, (void *)&first,
+                      (void *)&seeds, (void *)&indices, (void *)&gran, (void *)&status};
+      ProfScope prof(KC_FPS_STEP, st, 2.0 * batch * (double)n * C * (m - 1), 4.0 * batch * (double)n * C);
+      hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&fps_persistent_kernel),
+                                                dim3(batch * bpi), dim3(FPP_THREADS), args, (unsigned)lds, st);
+      if (e == hipSuccess) return UOC_OK;
+      (void)hipGetLastError();  // not co-resident on this device: fall through to the streaming path
+    }
+  }
   const int nblk = fps_blocks(n);
   for (int s = 0; s < m; ++s) {
     dim3 grid(nblk, batch);  // gridDim.x doubles as the partial count, so it is the same every step
@@ -646,6 +872,11 @@ static int run_assign(const float *X, int batch, int n, const float *Z, const in
 using namespace uoc;
 
 extern "C" {
+
+int uoc_ms_set_persistent_fps(int on) {
+  g_fps_persistent = on ? 1 : 0;
+  return UOC_OK;
+}
 
 size_t uoc_ms_workspace_bytes(int batch, int n, int m) {
   (void)m;
