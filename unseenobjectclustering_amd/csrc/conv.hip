@@ -464,7 +464,6 @@ static const TileCfg kCfgs[] = {
     {80, 128, 512, 1.06f},   // 1: 1x8 waves, wave tile 80x16
     {160, 64, 512, 1.06f},   // 2: 2x4 waves, wave tile 80x16
     {80, 64, 256, 1.12f},    // 3: 1x4 waves, wave tile 80x16
-    {80, 128, 256, 1.03f},   // 4: 1x4 waves, wave tile 80x32 — two such blocks share a CU and de-synchronise
 };
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kNumCU = 256;
@@ -526,14 +525,65 @@ struct Choice {
   int glds;
 };
 
+static const int kBmWide[4] = {96, 128, 160, 192};  // 2x4-wave families (wave tile BM/2 x 32|16)
+static const int kBmNarrow[3] = {64, 80, 96};       // 1x8 / 1x4-wave families (wave tile BM x 16)
+
+static int pick_bm(int M, int ntiles, int G, int BN, const int *cands, int n) {
+  static int fixed = -1;
+  if (fixed < 0) {
+    const char *e = getenv("UOC_CONV_FIXED_TILE");  // 1 = always the 160 / 80 tile (A/B measurements)
+    fixed = e ? atoi(e) : 0;
+  }
+  if (fixed) return cands == kBmWide ? 160 : 80;
+  int best = cands[n - 1];
+  double best_cost = -1;
+  for (int i = 0; i < n; ++i) {
+    const int bm = cands[i];
+    const long blocks = (long)((M + bm - 1) / bm) * ntiles * G;
+    const long rounds = (blocks + kNumCU - 1) / kNumCU;
+    // per-flop cost grows mildly as the tile shrinks (operand re-reads per MFMA)
+    const double cost = (double)rounds * bm * BN * (1.0 + 0.05 * ((double)cands[n - 1] / bm - 1.0));
+    if (best_cost < 0 || cost <= best_cost) {
+      best = bm;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
 static int launch_choice(const ConvParams &p, hipStream_t st, Choice c) {
   if (c.glds) {
+    // Each tile family (wave layout x BN) is instantiated for several pixel-tile heights; the one
+    // that packs (m-tiles x n-tiles x branches) best into whole rounds of 256 CUs is used, so the
+    // stage-2 shapes (784 x #ROIs pixels) do not lose 30-45 % to tile quantisation.
+    const int M = p.B * p.Ho * p.Wo;
     switch (c.cfg) {
-      case 0: return launch_glds<160, 128, 2, 4, false>(p, st, KC_GLDS_160x128);
-      case 1: return launch_glds<80, 128, 1, 8, false>(p, st, KC_GLDS_80x128);
-      case 2: return launch_glds<160, 64, 2, 4, false>(p, st, KC_GLDS_160x64);
-      case 3: return launch_glds<80, 64, 1, 4, false>(p, st, KC_GLDS_80x64);
-      case 4: return launch_glds<80, 128, 1, 4, false>(p, st, KC_GLDS_80x128);
+      case 0:
+        switch (pick_bm(M, p.Cout / 128, p.G, 128, kBmWide, 4)) {
+          case 96: return launch_glds<96, 128, 2, 4, false>(p, st, KC_GLDS_160x128);
+          case 128: return launch_glds<128, 128, 2, 4, false>(p, st, KC_GLDS_160x128);
+          case 192: return launch_glds<192, 128, 2, 4, false>(p, st, KC_GLDS_160x128);
+          default: return launch_glds<160, 128, 2, 4, false>(p, st, KC_GLDS_160x128);
+        }
+      case 1:
+        switch (pick_bm(M, p.Cout / 128, p.G, 128, kBmNarrow, 3)) {
+          case 64: return launch_glds<64, 128, 1, 8, false>(p, st, KC_GLDS_80x128);
+          case 96: return launch_glds<96, 128, 1, 8, false>(p, st, KC_GLDS_80x128);
+          default: return launch_glds<80, 128, 1, 8, false>(p, st, KC_GLDS_80x128);
+        }
+      case 2:
+        switch (pick_bm(M, p.Cout / 64, p.G, 64, kBmWide, 4)) {
+          case 96: return launch_glds<96, 64, 2, 4, false>(p, st, KC_GLDS_160x64);
+          case 128: return launch_glds<128, 64, 2, 4, false>(p, st, KC_GLDS_160x64);
+          case 192: return launch_glds<192, 64, 2, 4, false>(p, st, KC_GLDS_160x64);
+          default: return launch_glds<160, 64, 2, 4, false>(p, st, KC_GLDS_160x64);
+        }
+      case 3:
+        switch (pick_bm(M, p.Cout / 64, p.G, 64, kBmNarrow, 3)) {
+          case 64: return launch_glds<64, 64, 1, 4, false>(p, st, KC_GLDS_80x64);
+          case 96: return launch_glds<96, 64, 1, 4, false>(p, st, KC_GLDS_80x64);
+          default: return launch_glds<80, 64, 1, 4, false>(p, st, KC_GLDS_80x64);
+        }
     }
   } else {
     switch (c.cfg) {
@@ -541,7 +591,6 @@ static int launch_choice(const ConvParams &p, hipStream_t st, Choice c) {
       case 1: return launch_cfg<80, 128, 1, 8, false>(p, st, KC_CONV_80x128);
       case 2: return launch_cfg<160, 64, 2, 4, false>(p, st, KC_CONV_160x64);
       case 3: return launch_cfg<80, 64, 1, 4, false>(p, st, KC_CONV_80x64);
-      case 4: return launch_cfg<80, 128, 1, 4, false>(p, st, KC_CONV_80x128);
     }
   }
   set_error("conv: bad choice cfg=%d", c.cfg);
