@@ -374,6 +374,12 @@ __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__rest
     // VALU underneath.
     f32x4 Sv[ST];
     float wv[ST][4];
+    // The seed fragments are loop-invariant, and hipcc would hoist all 28 b128 reads (112 VGPRs) out
+    // of the tile loop, leaving one wave per SIMD.  An opaque zero offset keeps them as per-tile LDS
+    // reads (cheap: 28 KB per 224 MFMAs) so that two waves per SIMD fit and cover each other's stalls.
+    int zo = 0;
+    asm volatile("" : "+v"(zo));
+    const float *Zt = Zs + zo;
 #pragma unroll
     for (int i = 0; i < ST + 2; ++i) {
       if (i >= 1 && i - 1 < ST) {
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__rest
       for (int k = 0; k < 16; ++k) {
         if (i < ST) {
           const int v = k >> 2, e = k & 3;
-          const float4 zb = *reinterpret_cast<const float4 *>(Zs + (16 * i + t) * ZP + 16 * v + 4 * q);
+          const float4 zb = *reinterpret_cast<const float4 *>(Zt + (16 * i + t) * ZP + 16 * v + 4 * q);
           Sv[i] = mfma4(f4c(xa[v], e), f4c(zb, e), Sv[i]);
         }
         if (i >= 2) {
@@ -677,13 +683,13 @@ struct MsWorkspace {
 
 static int hc_blocks(int batch, int n) {
   const int ntile = (n + 15) / 16;
-  // one 4-wave block per CU: the kernel runs 1 wave/SIMD (335 registers), so more blocks only add
+  // two 4-wave blocks per CU (253 registers => 2 waves/SIMD, 57 KB LDS each); more blocks only add
   // prologue (Z -> LDS) / epilogue (partial reduce + 28 KB store) work and partial traffic
   static int target = 0;
   if (!target) {
     const char *e = getenv("UOC_HC_BLOCKS");
-    target = e ? atoi(e) : 256;
-    if (target < 1) target = 256;
+    target = e ? atoi(e) : 512;
+    if (target < 1) target = 512;
   }
   int nblk = target / (batch > 0 ? batch : 1);
   if (nblk < 8) nblk = 8;
