@@ -117,6 +117,38 @@ def make_e2e(ref):
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **out)
 
 
+def make_demo(ref):
+    """BASELINE config 1: one 640x480 RGB-D pair of the reference's data/demo through the reference's
+    own test_sample (real SEGNET, calibrated synthetic weights for both networks).  The PNG pair is
+    copied next to the fixture as INPUT DATA; expected outputs are the reference's label maps."""
+    import contextlib
+    import io
+    import json
+    import shutil
+    from unseenobjectclustering_amd import io as uio
+    demo = os.path.join(ref_harness.REFERENCE_ROOT, "data", "demo")
+    dst = os.path.join(HERE, "demo")
+    os.makedirs(dst, exist_ok=True)
+    for f in ("000002-color.png", "000002-depth.png", "camera_params.json"):
+        shutil.copy(os.path.join(demo, f), os.path.join(dst, f))
+        os.chmod(os.path.join(dst, f), 0o644)
+    cam = json.load(open(os.path.join(dst, "camera_params.json")))
+    sample = uio.read_sample(os.path.join(dst, "000002-color.png"), os.path.join(dst, "000002-depth.png"), cam)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ref.networks.__dict__["seg_resnet34_8s_embedding"](2, 64, sd).eval()
+        net_crop = ref.networks.__dict__["seg_resnet34_8s_embedding"](2, 64, sd).eval()
+    np.random.seed(RNG_SEED)
+    with torch.no_grad():
+        out_label, refined = ref.test_dataset.test_sample(sample, net, net_crop)
+        feat = net(sample["image_color"], None, sample["depth"])
+    pos = sample_positions(7, 480 * 640, 1024)
+    np.savez_compressed(os.path.join(HERE, "demo.npz"), out_label=out_label.numpy().astype(np.uint8),
+                        refined=refined.numpy().astype(np.uint8), pos=pos,
+                        embed=feat.permute(0, 2, 3, 1).reshape(-1, 64)[pos].numpy().astype(np.float32))
+    print("demo: labels", np.unique(out_label.numpy()).tolist(), "refined", np.unique(refined.numpy()).tolist(), flush=True)
+
+
 def main():
     assert ref_harness.available(), "reference tree not present: golden vectors can only be made in the build container"
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -130,6 +162,8 @@ def main():
         make_glue(ref)
     if what in ("e2e", "all"):
         make_e2e(ref)
+    if what in ("demo", "all"):
+        make_demo(ref)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,47 @@
+"""Input preparation of the demo driver — mirror of tools/test_images.py:96-135 in the reference
+(`compute_xyz`, `read_sample`): BGR uint8 image -> /255 - PIXEL_MEANS/255 -> [1,3,H,W]; uint16
+millimetre depth -> metres -> XYZ point-cloud image with the pinhole model -> [1,3,H,W].
+PIL replaces cv2 (not installed here): PIL decodes RGB, cv2.imread returns BGR, hence the flip."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .fcn.config import cfg
+
+
+def compute_xyz(depth_img, fx, fy, px, py, height, width):
+    """tools/test_images.py:96-102.  depth_img [H,W] float32 metres -> [H,W,3] (x, y, z)."""
+    indices = np.indices((height, width), dtype=np.float32).transpose(1, 2, 0)   # [..., 0] = y, [..., 1] = x
+    z_e = depth_img
+    x_e = (indices[..., 1] - px) * z_e / fx
+    y_e = (indices[..., 0] - py) * z_e / fy
+    return np.stack([x_e, y_e, z_e], axis=-1)
+
+
+def load_images(filename_color, filename_depth):
+    from PIL import Image
+    im = np.asarray(Image.open(filename_color).convert("RGB"))[:, :, ::-1].copy()     # BGR like cv2.imread (:108)
+    depth_img = np.asarray(Image.open(filename_depth)) if filename_depth is not None else None   # uint16 mm (:112)
+    return im, depth_img
+
+
+def make_sample(im_bgr_u8, depth_u16, camera_params):
+    """tools/test_images.py:112-133 on decoded arrays."""
+    sample = {}
+    if cfg.INPUT in ("DEPTH", "RGBD"):
+        depth = depth_u16.astype(np.float32) / 1000.0
+        height, width = depth.shape
+        xyz_img = compute_xyz(depth, camera_params["fx"], camera_params["fy"], camera_params["x_offset"],
+                              camera_params["y_offset"], height, width)
+        sample["depth"] = torch.from_numpy(xyz_img).permute(2, 0, 1).unsqueeze(0)
+    im_tensor = torch.from_numpy(im_bgr_u8) / 255.0
+    im_tensor -= torch.tensor(cfg.PIXEL_MEANS / 255.0).float()
+    sample["image_color"] = im_tensor.permute(2, 0, 1).unsqueeze(0)
+    return sample
+
+
+def read_sample(filename_color, filename_depth, camera_params):
+    """tools/test_images.py:105-135."""
+    im, depth_img = load_images(filename_color, filename_depth)
+    return make_sample(im, depth_img, camera_params)
