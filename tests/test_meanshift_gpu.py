@@ -144,3 +144,31 @@ def test_persistent_and_streaming_seed_selection_agree(device, shape, batch):
     finally:
         L.uoc_ms_set_persistent_fps(1)
     assert torch.equal(i1, i0) and torch.equal(l1, l0)
+
+
+@pytest.mark.parametrize("n,m", [(50, 100), (1, 100), (200, 1), (130, 128), (4097, 17)])
+def test_ragged_and_tiny_inputs_vs_oracle(device, n, m):
+    """Fewer points than seeds (duplicate seeds, every distance ties), a single point, a single seed,
+    the maximum seed count, and sizes that are not multiples of any tile."""
+    rng = np.random.default_rng(n * 1000 + m)
+    c = rng.standard_normal((3, 64)).astype(np.float32)
+    x = c[rng.integers(0, 3, n)] + 0.05 * rng.standard_normal((n, 64)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    first = int(rng.integers(0, n))
+    lo, io, parts = O.mean_shift_smart_init(torch.from_numpy(x), KAPPA, m, 10, first_index=first, epsilon=EPSILON,
+                                            return_parts=True)
+    labels, idx, Z, sl = MS.cluster_batch(torch.from_numpy(x).to(device)[None], [first], KAPPA, m, 10, EPSILON,
+                                          return_parts=True)
+    assert np.array_equal(idx[0].cpu().numpy(), io.numpy())
+    assert np.abs(Z[0].cpu().numpy() - parts["Z"].numpy()).max() < Z_TOL
+    assert np.array_equal(sl[0].cpu().numpy(), parts["seed_labels"].numpy())
+    assert np.array_equal(labels[0].cpu().numpy(), lo.numpy())
+
+
+def test_argument_errors_are_reported(device):
+    from unseenobjectclustering_amd import _native
+    X = torch.nn.functional.normalize(torch.randn(1, 256, 64, device=device), dim=2)
+    with pytest.raises(_native.NativeError):
+        MS.cluster_batch(X, [0], KAPPA, 129, 10, EPSILON)            # num_seeds > UOC_MAX_SEEDS
+    with pytest.raises(NotImplementedError):
+        MS.cluster_batch(torch.zeros(1, 256, 32, device=device), [0])   # d != 64
