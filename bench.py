@@ -111,8 +111,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("UOC_BENCH_FORCE_DIST") == "1"   # FORCE: exercise the RCCL path on 1 GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from unseenobjectclustering_amd import _native, networks, runner, synth
@@ -131,27 +133,38 @@ def main():
     def run(nsteps, gather):
         # frames of this rank: global indices rank*nsteps .. (weak scaling: fixed work per GPU)
         total = nsteps * world
-        maps = runner.run_sharded(total, lambda i: frame_fn(i - rank * nsteps), H, W, device, rank, world, gather)
+        maps = runner.run_sharded(total, lambda i: frame_fn(i - rank * nsteps), H, W, device, rank, world, gather,
+                                  force_collective=use_dist)
         return maps.cpu()           # label-map block lands on the host inside the timed region
 
     print(f"[bench] rank {rank}: nets built, {distinct} frames resident, warming up", file=sys.stderr, flush=True)
     if args.warmup > 0:
-        run(args.warmup, world > 1)
+        run(args.warmup, use_dist)
     print(f"[bench] rank {rank}: warmup done", file=sys.stderr, flush=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
-    maps = run(K, world > 1)
+    maps = run(K, use_dist)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     objects = float(np.mean([int(m.max()) for m in maps[:K]]))
+    pcie = None
+    if rank == 0 and world == 1 and os.environ.get("UOC_BENCH_PCIE") == "1":
+        # informative only (never `value`): the same frames, but uploaded from pageable host memory per frame
+        host = [dict(image_color=s_["image_color"].cpu(), depth=s_["depth"].cpu()) for s_ in samples]
+        fn2 = runner.two_stage_frame_fn(host, network, network_crop)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        runner.run_sharded(K, fn2, H, W, device, 0, 1, False).cpu()
+        torch.cuda.synchronize()
+        pcie = round(K / (time.perf_counter() - t1), 3)
     print(f"[bench] rank {rank}: timed region {dt:.3f}s", file=sys.stderr, flush=True)
 
     # ---- profiled pass (HIP events around every launch; separate from the timed region) ----
@@ -201,11 +214,12 @@ def main():
             "config": {"workload": "configs[3]: full two-stage (crop-and-refine) segmentation, 640x480 RGB-D, batch 1"
                                    + ("" if world == 1 else f"; configs[4]: frames sharded over {world} GPUs + RCCL all_gather"),
                        "frame": "640x480", "seeds": 100, "iters": 10, "crop": 224,
-                       "mean_final_objects": round(objects, 2), "frames_per_gpu": K},
+                       "mean_final_objects": round(objects, 2), "frames_per_gpu": K,
+                       **({"pcie_inclusive_frames_per_s": pcie} if pcie is not None else {})},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

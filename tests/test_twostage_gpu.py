@@ -81,3 +81,39 @@ def test_no_objects_returns_none(device):
     one[:, 0] = 1.0
     out_label, refined = TD.test_sample(sample, lambda i, l, d: one, lambda i, l, d: one)
     assert refined is None and float(out_label.abs().max()) == 0.0
+
+
+def test_test_segnet_loop_writes_mat_files(device, tmp_path):
+    """test_segnet (test_dataset.py:271-381): loader loop, per-sample .mat with labels / labels_refined /
+    filename (:337-340); dataset name 'osd' selects the 0.8 depth filter (:303-305)."""
+    import scipy.io
+    cfg.device = device
+
+    class Loader(list):
+        class dataset:
+            name = "osd_object_test"
+
+    samples = Loader()
+    for s in (61, 62):
+        fr = synth.rgbd_frame(s, 120, 160, 2)
+        samples.append(dict(image_color=torch.from_numpy(fr["image_color"]), depth=torch.from_numpy(fr["depth"]),
+                            label=torch.zeros(1, 120, 160), filename="frame%d" % s))
+
+    class Net:
+        def __init__(self, seed):
+            self.seed = seed
+
+        def eval(self):
+            return self
+
+        def __call__(self, img, label, depth):
+            B, _, h, w = img.shape
+            return torch.cat([e2e_stub_features(self.seed + k, h, w, 3) for k in range(B)]).to(device)
+
+    np.random.seed(3)
+    res = TD.test_segnet(samples, Net(70), str(tmp_path), Net(80))
+    assert len(res) == 2
+    for i in range(2):
+        m = scipy.io.loadmat(os.path.join(str(tmp_path), "%06d.mat" % i))
+        assert m["labels"].shape == (120, 160) and m["labels_refined"].shape == (120, 160)
+        assert np.array_equal(m["labels"], res[i]["labels"])

@@ -30,7 +30,8 @@ def frame_rng_seed(frame_index: int) -> int:
 
 
 def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height: int, width: int,
-                device: torch.device, rank: int = 0, world: int = 1, gather: bool = True) -> Optional[torch.Tensor]:
+                device: torch.device, rank: int = 0, world: int = 1, gather: bool = True,
+                force_collective: bool = False) -> Optional[torch.Tensor]:
     """Runs frame_fn(global_index) -> [H,W] integer label map (on `device`) for this rank's block
     and all-gathers the uint8 blocks.  Returns [num_frames, H, W] uint8 on `device` (every rank),
     or only the local block when gather=False / world == 1."""
@@ -40,7 +41,7 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     for i in range(lo, hi):
         np.random.seed(frame_rng_seed(i))
         block[i - lo] = frame_fn(i).to(torch.uint8)
-    if world == 1 or not gather:
+    if (world == 1 and not force_collective) or not gather:
         return block[:hi - lo]
     full = torch.empty((world * per, height, width), dtype=torch.uint8, device=device)
     dist.all_gather_into_tensor(full, block)
