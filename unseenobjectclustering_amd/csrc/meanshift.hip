@@ -768,33 +768,56 @@ static int fps_persistent_plan(int batch, int n, int *bpi, int *nslots) {
   return 1;
 }
 
+static int run_select_seeds_streaming(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
+                                      int32_t *indices, const MsWorkspace &w, hipStream_t st);
+
 static int run_select_seeds(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
                             int32_t *indices, const MsWorkspace &w, hipStream_t st) {
-  int bpi = 0, nslots = 0;
-  if (m >= 2 && fps_persistent_plan(batch, n, &bpi, &nslots)) {
+  // Persistent path: as many items per cooperative launch as stay co-resident; a larger batch
+  // (stage 2 with > 8 ROIs) is split into several launches rather than dropped to the streaming kernel.
+  int done = 0;
+  while (m >= 2 && done < batch) {
+    int sub = batch - done, bpi = 0, nslots = 0;
+    while (sub > 1 && !fps_persistent_plan(sub, n, &bpi, &nslots)) sub = (sub + 1) / 2;
+    if (!fps_persistent_plan(sub, n, &bpi, &nslots)) break;
     unsigned long long *gran = reinterpret_cast<unsigned long long *>(w.part[0]);
     int *status = reinterpret_cast<int *>(w.part[1]);
-    const size_t gbytes = (size_t)2 * batch * bpi * sizeof(unsigned long long);
-    if (gbytes <= (size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax)) {
-      UOC_HIP_CHECK(hipMemsetAsync(gran, 0, gbytes, st));   // tag 0 = "not published": re-initialised every call
-      UOC_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int), st));
-      const size_t lds = (size_t)FPP_WAVES * FPP_LS * (64 * sizeof(float4) + 4 * sizeof(float));
-      static bool attr_set = false;
-      if (!attr_set) {
-        UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_persistent_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-      }
-      const float *Xc = X;
-      void *args[] = {(void *)&Xc, (void *)&n, (void *)&m, (void *)&bpi, (void *)&nslots, (void *)&first,
-                      (void *)&seeds, (void *)&indices, (void *)&gran, (void *)&status};
-      ProfScope prof(KC_FPS_STEP, st, 2.0 * batch * (double)n * C * (m - 1), 4.0 * batch * (double)n * C);
-      hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&fps_persistent_kernel),
-                                                dim3(batch * bpi), dim3(FPP_THREADS), args, (unsigned)lds, st);
-      if (e == hipSuccess) return UOC_OK;
-      (void)hipGetLastError();  // not co-resident on this device: fall through to the streaming path
+    const size_t gbytes = (size_t)2 * sub * bpi * sizeof(unsigned long long);
+    if (gbytes > (size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax)) break;
+    UOC_HIP_CHECK(hipMemsetAsync(gran, 0, gbytes, st));  // tag 0 = "not published": re-initialised every call
+    UOC_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int), st));
+    const size_t lds = (size_t)FPP_WAVES * FPP_LS * (64 * sizeof(float4) + 4 * sizeof(float));
+    static bool attr_set = false;
+    if (!attr_set) {
+      UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_persistent_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
     }
+    const float *Xc = X + (size_t)done * n * C;
+    const int32_t *fc = first + done;
+    float *sc = seeds + (size_t)done * m * C;
+    int32_t *ic = indices + (size_t)done * m;
+    void *args[] = {(void *)&Xc, (void *)&n, (void *)&m, (void *)&bpi, (void *)&nslots, (void *)&fc,
+                    (void *)&sc, (void *)&ic, (void *)&gran, (void *)&status};
+    hipError_t e;
+    {
+      ProfScope prof(KC_FPS_STEP, st, 2.0 * sub * (double)n * C * (m - 1), 4.0 * sub * (double)n * C);
+      e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&fps_persistent_kernel), dim3(sub * bpi),
+                                     dim3(FPP_THREADS), args, (unsigned)lds, st);
+    }
+    if (e != hipSuccess) {
+      (void)hipGetLastError();  // not co-resident on this device: the rest goes to the streaming path
+      break;
+    }
+    done += sub;
   }
+  if (done >= batch) return UOC_OK;
+  return run_select_seeds_streaming(X + (size_t)done * n * C, batch - done, n, m, first + done,
+                                    seeds + (size_t)done * m * C, indices + (size_t)done * m, w, st);
+}
+
+static int run_select_seeds_streaming(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
+                                      int32_t *indices, const MsWorkspace &w, hipStream_t st) {
   const int nblk = fps_blocks(n);
   for (int s = 0; s < m; ++s) {
     dim3 grid(nblk, batch);  // gridDim.x doubles as the partial count, so it is the same every step
