@@ -12,7 +12,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.path.join(PKG_DIR, "libuoc_hip.so")
+LIB_PATH = os.environ.get("UOC_LIB_PATH") or os.path.join(PKG_DIR, "libuoc_hip.so")   # override: dev builds only
 ARCH = "gfx950"
 
 

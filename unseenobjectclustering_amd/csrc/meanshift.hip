@@ -143,22 +143,45 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
 
 // -------------------------------------------------------------------------------------------
 // Persistent farthest-point sampling: ONE launch for all m steps.  Every block keeps its share of
-// X resident on chip for the whole call — 36 pixel-slots per wave in VGPRs (4 pixels x 16 lanes x
-// float4 each) plus up to 18 in LDS, i.e. up to 1728 pixels per CU — so a step costs no HBM/L2 traffic at
-// all, only the dot products and a grid-wide argmax.  The argmax exchange is a tagged-granule
+// X resident on chip for the whole call: each LANE owns up to 3 whole pixels in VGPRs (3 x 64 floats)
+// plus one in LDS, i.e. up to 2048 pixels per CU, so a step costs no HBM/L2 traffic — the new seed
+// row is 64 wave-uniform scalars and a pixel's distance is a private 64-FMA chain (no cross-lane
+// reduction at all; ~1 VALU instruction per pixel-channel).  The grid-wide argmax is a tagged-granule
 // all-gather (MI355X_MICROARCH "R2": the 8-byte {value, index|tag} word written with ONE agent-scope
 // atomic store is its own flag; no fences, no counters): each block publishes its (max, lowest
 // index) for step s in slot [s&1][block], one wave per block sweeps the row until every tag equals
 // s+1.  Two slots suffice: a block can only be one step ahead of the slowest reader.
-// Placement independent; needs all blocks co-resident => launched cooperatively with
-// grid <= #CUs (512-thread blocks with a 256-register budget, one per CU); every spin is bounded and sets *status on expiry.
+// Placement independent; needs all blocks co-resident => launched cooperatively with grid <= #CUs
+// (512-thread blocks, one per CU); every spin is bounded and sets *status on expiry.
+// Measured per step (480x640, 256 blocks): exchange ~3.2 us, compute + block reduce ~1.3 us.
 // -------------------------------------------------------------------------------------------
 constexpr int FPP_THREADS = 512;
 constexpr int FPP_WAVES = FPP_THREADS / 64;
-constexpr int FPP_RS = 36;  // register slots per wave
-constexpr int FPP_LS = 18;  // LDS slots per wave
+constexpr int FPP_RS = 3;  // pixels per lane held in registers
+constexpr int FPP_LS = 1;  // pixels per lane held in LDS
 constexpr int FPP_SLOTS = FPP_RS + FPP_LS;
-constexpr int FPP_PIX_PER_BLOCK = FPP_WAVES * FPP_SLOTS * 4;  // 1728
+constexpr int FPP_PIX_PER_BLOCK = FPP_THREADS * FPP_SLOTS;  // 2048
+
+// Wave-wide argmax with torch semantics (max value, ties -> lowest index), result wave-uniform.
+// DPP row reductions (every lane of a 16-lane row ends with the row result) + 4 v_readlane.
+__device__ __forceinline__ ArgMax wave_argmax_fast(ArgMax a) {
+  float v = a.val;
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  const int vi = __float_as_int(v);
+  const float m = fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(vi, 0)), __int_as_float(__builtin_amdgcn_readlane(vi, 16))),
+                        fmaxf(__int_as_float(__builtin_amdgcn_readlane(vi, 32)), __int_as_float(__builtin_amdgcn_readlane(vi, 48))));
+  int i = (a.val == m) ? a.idx : INT_MAX;
+  i = min(i, dpp_i<0xB1>(i));
+  i = min(i, dpp_i<0x4E>(i));
+  i = min(i, dpp_i<0x141>(i));
+  i = min(i, dpp_i<0x140>(i));
+  const int mi = min(min(__builtin_amdgcn_readlane(i, 0), __builtin_amdgcn_readlane(i, 16)),
+                     min(__builtin_amdgcn_readlane(i, 32), __builtin_amdgcn_readlane(i, 48)));
+  return ArgMax{m, mi};
+}
 
 __device__ __forceinline__ unsigned long long fpp_pack(float val, int idx, int tag) {
   return ((unsigned long long)__float_as_uint(val) << 32) | (unsigned)(idx & 0xFFFFFF) | ((unsigned)(tag & 0xFF) << 24);
@@ -167,7 +190,7 @@ __device__ __forceinline__ unsigned long long fpp_pack(float val, int idx, int t
 __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
     const float *__restrict__ X, int n, int m, int bpi, int nslots, const int *__restrict__ first_index,
     float *__restrict__ seeds, int *__restrict__ indices, unsigned long long *gran, int *status) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [FPP_WAVES][FPP_LS][64 lanes] float4
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [FPP_LS][16 float4-chunks][FPP_THREADS] float4
   __shared__ ArgMax red[FPP_WAVES];
   __shared__ int s_idx;
   const int item = blockIdx.x / bpi, blk = blockIdx.x - item * bpi;
@@ -175,86 +198,95 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
   seeds += (size_t)item * m * C;
   indices += (size_t)item * m;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = lane & 15, g = lane >> 4;
-  const int ppb = FPP_WAVES * nslots * 4;                    // pixels owned by one block
-  const int pbase = blk * ppb + wave * nslots * 4 + g;       // + 4*slot
-  float4 *lds = reinterpret_cast<float4 *>(smem) + (size_t)wave * FPP_LS * 64 + lane;
-  float *lds_dm = smem + (size_t)FPP_WAVES * FPP_LS * 64 * 4 + wave * FPP_LS * 4;  // [wave][slot][g]
+  // pixel of (slot j, thread tid): consecutive threads own consecutive pixels; slots ascend per lane
+  const int pbase = blk * (FPP_THREADS * nslots) + tid;  // + j * FPP_THREADS
+  float4 *lds = reinterpret_cast<float4 *>(smem) + tid;  // chunk c4 at lds[c4 * FPP_THREADS]
 
-  // ---- load this wave's pixels once -----------------------------------------------------------
-  float4 x[FPP_RS];
+  // ---- load this thread's pixels once -------------------------------------------------------
+  float x[FPP_RS][C];
 #pragma unroll
-  for (int i = 0; i < FPP_RS; ++i) {
-    const int p = pbase + 4 * i;
-    x[i] = (i < nslots && p < n) ? *reinterpret_cast<const float4 *>(X + (size_t)p * C + 4 * t)
-                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  for (int i = FPP_RS; i < nslots; ++i) {
-    const int p = pbase + 4 * i;
-    lds[(i - FPP_RS) * 64] = (p < n) ? *reinterpret_cast<const float4 *>(X + (size_t)p * C + 4 * t)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  float dm[(FPP_RS + 15) / 16];
+  for (int j = 0; j < FPP_RS; ++j) {
+    const int p = pbase + j * FPP_THREADS;
+    const bool ok = j < nslots && p < n;
 #pragma unroll
-  for (int i = 0; i < (FPP_RS + 15) / 16; ++i) dm[i] = 0.f;  // running min distance of slot i lives in lane t == (i & 15), register i >> 4
+    for (int c4 = 0; c4 < C / 4; ++c4) {
+      const float4 v = ok ? *reinterpret_cast<const float4 *>(X + (size_t)p * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[j][4 * c4 + 0] = v.x;
+      x[j][4 * c4 + 1] = v.y;
+      x[j][4 * c4 + 2] = v.z;
+      x[j][4 * c4 + 3] = v.w;
+    }
+  }
+  if (nslots > FPP_RS) {
+    const int p = pbase + FPP_RS * FPP_THREADS;
+#pragma unroll
+    for (int c4 = 0; c4 < C / 4; ++c4)
+      lds[c4 * FPP_THREADS] = (p < n) ? *reinterpret_cast<const float4 *>(X + (size_t)p * C + 4 * c4)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float dm[FPP_SLOTS];
+#pragma unroll
+  for (int j = 0; j < FPP_SLOTS; ++j) dm[j] = 0.f;
 
-  int cur = first_index[item];
+  int cur = __builtin_amdgcn_readfirstlane(first_index[item]);
   if (blk == 0) {
     if (tid == 0) indices[0] = cur;
     if (tid < 16) *reinterpret_cast<float4 *>(seeds + 4 * tid) = *reinterpret_cast<const float4 *>(X + (size_t)cur * C + 4 * tid);
   }
+#ifdef UOC_FPS_TIMING
+  unsigned long long tc_comp = 0, tc_red = 0, tc_sweep = 0, tc_tail = 0;
+#define UOC_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define UOC_T(v)
+#endif
   for (int step = 0; step + 1 < m; ++step) {
-    const float4 sv = *reinterpret_cast<const float4 *>(X + (size_t)cur * C + 4 * t);
+    UOC_T(t1_);
+    // the seed row: `cur` is wave-uniform, so these are scalar loads and the FMAs take SGPR operands
+    const float *__restrict__ srow = X + (size_t)cur * C;
     ArgMax best = {-INFINITY, INT_MAX};
-#define UOC_FPP_SLOT(I, XV)                                                      \
-  {                                                                              \
-    float s_ = (XV).x * sv.x;                                                    \
-    s_ = fmaf((XV).y, sv.y, s_);                                                 \
-    s_ = fmaf((XV).z, sv.z, s_);                                                 \
-    s_ = fmaf((XV).w, sv.w, s_);                                                 \
-    s_ = row16_sum(s_);                                                          \
-    if (t == ((I)&15)) {                                                         \
-      float d_ = 0.5f * (1.0f - s_);                                             \
-      if (step > 0) d_ = fminf(d_, dm[(I) >> 4]);                                \
-      dm[(I) >> 4] = d_;                                                         \
-      const int p_ = pbase + 4 * (I);                                            \
-      if (p_ < n && d_ > best.val) { /* slots ascend per lane: '>' keeps the lowest index */ \
-        best.val = d_;                                                           \
-        best.idx = p_;                                                           \
-      }                                                                          \
-    }                                                                            \
-  }
 #pragma unroll
-    for (int i = 0; i < FPP_RS; ++i)
-      if (i < nslots) UOC_FPP_SLOT(i, x[i])
-    // LDS-resident slots: rolled loop (keeps register pressure flat); their running minima live in LDS
-#pragma unroll 2
-    for (int i = FPP_RS; i < nslots; ++i) {
-      const float4 xv = lds[(i - FPP_RS) * 64];
-      float s_ = xv.x * sv.x;
-      s_ = fmaf(xv.y, sv.y, s_);
-      s_ = fmaf(xv.z, sv.z, s_);
-      s_ = fmaf(xv.w, sv.w, s_);
-      s_ = row16_sum(s_);
-      if (t == 0) {
-        float *dmp = lds_dm + (i - FPP_RS) * 4 + g;
+    for (int j = 0; j < FPP_RS; ++j) {
+      if (j < nslots) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) s_ = fmaf(x[j][c], srow[c], s_);
         float d_ = 0.5f * (1.0f - s_);
-        if (step > 0) d_ = fminf(d_, *dmp);
-        *dmp = d_;
-        const int p_ = pbase + 4 * i;
-        if (p_ < n && d_ > best.val) {
+        if (step > 0) d_ = fminf(d_, dm[j]);
+        dm[j] = d_;
+        const int p_ = pbase + j * FPP_THREADS;
+        if (p_ < n && d_ > best.val) {  // slots ascend per lane: '>' keeps the lowest index
           best.val = d_;
           best.idx = p_;
         }
       }
     }
-#undef UOC_FPP_SLOT
-    best = wave_argmax(best);
+    if (nslots > FPP_RS) {
+      float s_ = 0.f;
+#pragma unroll
+      for (int c4 = 0; c4 < C / 4; ++c4) {
+        const float4 v = lds[c4 * FPP_THREADS];
+        s_ = fmaf(v.x, srow[4 * c4 + 0], s_);
+        s_ = fmaf(v.y, srow[4 * c4 + 1], s_);
+        s_ = fmaf(v.z, srow[4 * c4 + 2], s_);
+        s_ = fmaf(v.w, srow[4 * c4 + 3], s_);
+      }
+      float d_ = 0.5f * (1.0f - s_);
+      if (step > 0) d_ = fminf(d_, dm[FPP_RS]);
+      dm[FPP_RS] = d_;
+      const int p_ = pbase + FPP_RS * FPP_THREADS;
+      if (p_ < n && d_ > best.val) {
+        best.val = d_;
+        best.idx = p_;
+      }
+    }
+    UOC_T(t2_);
+    best = wave_argmax_fast(best);
     if (lane == 0) red[wave] = best;
     __syncthreads();
+    UOC_T(t3_);
     if (wave == 0) {
       ArgMax b2 = lane < FPP_WAVES ? red[lane] : ArgMax{-INFINITY, INT_MAX};
-      b2 = wave_argmax(b2);
+      b2 = wave_argmax_fast(b2);
       unsigned long long *row = gran + ((size_t)(step & 1) * gridDim.x + (size_t)item * bpi);
       const int tag = (step + 1) & 0xFF;
       if (lane == 0) __hip_atomic_store(row + blk, fpp_pack(b2.val, b2.idx, tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -265,17 +297,25 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
       while (!done) {
         bool ok = true;
         ArgMax a = {-INFINITY, INT_MAX};
-        for (int k = lane; k < bpi; k += 64) {
-          const unsigned long long v = __hip_atomic_load(row + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long gv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)  // bpi <= 256: all of this lane's polls are in flight together
+          gv[k] = (lane + 64 * k < bpi) ? __hip_atomic_load(row + lane + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : ((unsigned long long)tag << 24);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned long long v = gv[k];
           ok &= (int)((v >> 24) & 0xFF) == tag;
-          ArgMax c = {__uint_as_float((unsigned)(v >> 32)), (int)(v & 0xFFFFFF)};
-          if (better(c, a)) a = c;
+          if (lane + 64 * k < bpi) {
+            ArgMax c = {__uint_as_float((unsigned)(v >> 32)), (int)(v & 0xFFFFFF)};
+            if (better(c, a)) a = c;
+          }
         }
         if (__all(ok)) {
           acc = a;
           done = true;
         } else {
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(1);
           if (++spins > (1u << 22) || (((spins & 1023) == 0) && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
             if (lane == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             acc = ArgMax{0.f, 0};
@@ -283,11 +323,12 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
           }
         }
       }
-      acc = wave_argmax(acc);
+      acc = wave_argmax_fast(acc);
       if (lane == 0) s_idx = acc.idx;
     }
     __syncthreads();
-    cur = s_idx;
+    UOC_T(t4_);
+    cur = __builtin_amdgcn_readfirstlane(s_idx);
     if (cur < 0 || cur >= n) cur = 0;  // only reachable after a timeout
     if (blk == 0) {
       if (tid == 0) indices[step + 1] = cur;
@@ -295,7 +336,20 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
         *reinterpret_cast<float4 *>(seeds + (size_t)(step + 1) * C + 4 * tid) =
             *reinterpret_cast<const float4 *>(X + (size_t)cur * C + 4 * tid);
     }
+#ifdef UOC_FPS_TIMING
+    const unsigned long long t5_ = __builtin_amdgcn_s_memtime();
+    tc_comp += t2_ - t1_;
+    tc_red += t3_ - t2_;
+    tc_sweep += t4_ - t3_;
+    tc_tail += t5_ - t4_;
+#endif
   }
+#ifdef UOC_FPS_TIMING
+  if ((blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && tid == 0)
+    printf("[fps timing blk %d] per step (cycles): compute %.1f reduce %.1f sweep %.1f tail %.1f\n", (int)blockIdx.x,
+           tc_comp / (double)(m - 1), tc_red / (double)(m - 1), tc_sweep / (double)(m - 1), tc_tail / (double)(m - 1));
+#endif
+#undef UOC_T
 }
 
 // -------------------------------------------------------------------------------------------
@@ -759,10 +813,10 @@ static int fps_persistent_plan(int batch, int n, int *bpi, int *nslots) {
   if (b < 1) return 0;
   if (b > 256) b = 256;
   const int per_block = (n + b - 1) / b;
-  int ns = (per_block + FPP_WAVES * 4 - 1) / (FPP_WAVES * 4);
-  if (ns > FPP_SLOTS) return 0;  // does not fit on chip: use the streaming kernel
+  int ns = (per_block + FPP_THREADS - 1) / FPP_THREADS;  // pixels per lane
+  if (ns > FPP_SLOTS) return 0;  // does not fit on chip: split the batch / use the streaming kernel
   if (ns < 1) ns = 1;
-  b = (n + FPP_WAVES * ns * 4 - 1) / (FPP_WAVES * ns * 4);  // drop blocks that would own no pixel
+  b = (n + FPP_THREADS * ns - 1) / (FPP_THREADS * ns);  // drop blocks that would own no pixel
   *bpi = b;
   *nslots = ns;
   return 1;
@@ -786,7 +840,7 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
     if (gbytes > (size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax)) break;
     UOC_HIP_CHECK(hipMemsetAsync(gran, 0, gbytes, st));  // tag 0 = "not published": re-initialised every call
     UOC_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int), st));
-    const size_t lds = (size_t)FPP_WAVES * FPP_LS * (64 * sizeof(float4) + 4 * sizeof(float));
+    const size_t lds = (size_t)FPP_LS * (C / 4) * FPP_THREADS * sizeof(float4);
     static bool attr_set = false;
     if (!attr_set) {
       UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_persistent_kernel),
