@@ -244,7 +244,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, int VARIANT = 0>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvParams p, int ntiles, int mtiles) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -372,23 +372,36 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
   }
   __builtin_amdgcn_s_barrier();
   UOC_FRAG2(0, 0, wa0, xb0)
+  if (VARIANT >= 3) UOC_FRAG2(0, 1, wa1, xb1)
   int s_cur = 0, s_nxt = 1, s_nn = 2;  // ring positions of chunks kc, kc+1, kc+2
+  const bool early = wave < (WAVES_M * WAVES_N) / 2;
   static_assert(NPASS <= 8, "DMA passes per chunk");
   for (int kc = 0; kc < nk; ++kc) {
     // (Spreading the DMAs between the MFMA groups was measured 5-15 % SLOWER than this burst.)
-    if (kc + 2 < nk) UOC_ISSUE(kc + 2, s_nn)
-    UOC_FRAG2(s_cur, 1, wa1, xb1)
+    // VARIANT != 0: timing ablations only (wrong results): 1 = no DMA in the loop, 2 = also no barrier /
+    // waits, 3 = also no fragment reads.
+    // The DMA burst (address VALU + 5 LDS-DMAs) is issued BEFORE the h=0 MFMAs by the first half of
+    // the waves and AFTER them by the second half (waves w and w+NW/2 share a SIMD), so the two waves
+    // of a SIMD never do their address arithmetic at the same time.  Same vmcnt accounting either way.
+    // Ablation (layer4 shape): removing the DMAs altogether is worth +12 %, the barrier +3 %, the
+    // fragment reads +4 %; the stagger itself measured neutral, i.e. the DMA cost is not issue-slot
+    // contention (suspected: L2->LDS traffic lowers the sustained clock under the power cap).
+    if (kc + 2 < nk && VARIANT < 1 && early) UOC_ISSUE(kc + 2, s_nn)
+    if (VARIANT < 3) UOC_FRAG2(s_cur, 1, wa1, xb1)
     UOC_MFMA_E(wa0, xb0, x)
     UOC_MFMA_E(wa0, xb0, y)
     UOC_MFMA_E(wa0, xb0, z)
     UOC_MFMA_E(wa0, xb0, w)
-    if (kc + 2 < nk)
-      wait_vmcnt<NPASS>();  // chunk kc+1 has landed; chunk kc+2 may still be in flight
-    else
-      wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kc + 1 < nk) UOC_FRAG2(s_nxt, 0, wa0, xb0)
+    if (kc + 2 < nk && VARIANT < 1 && !early) UOC_ISSUE(kc + 2, s_nn)
+    if (VARIANT < 2) {
+      if (kc + 2 < nk)
+        wait_vmcnt<NPASS>();  // chunk kc+1 has landed; chunk kc+2 may still be in flight
+      else
+        wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    if (kc + 1 < nk && VARIANT < 3) UOC_FRAG2(s_nxt, 0, wa0, xb0)
     UOC_MFMA_E(wa1, xb1, x)
     UOC_MFMA_E(wa1, xb1, y)
     UOC_MFMA_E(wa1, xb1, z)
@@ -431,7 +444,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
   }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, int VARIANT = 0>
 static int launch_glds(const ConvParams &p, hipStream_t st, int kc) {
   const int M = p.B * p.Ho * p.Wo;
   const double taps = (double)p.KH * p.KW;
@@ -443,12 +456,12 @@ static int launch_glds(const ConvParams &p, hipStream_t st, int kc) {
   const size_t lds = (size_t)3 * (BM + BN) * BK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_kernel<BM, BN, WAVES_M, WAVES_N, STEM>),
+    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_kernel<BM, BN, WAVES_M, WAVES_N, STEM, VARIANT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   const int total = mtiles * ntiles * p.G;
-  hipLaunchKernelGGL((conv_glds_kernel<BM, BN, WAVES_M, WAVES_N, STEM>), dim3(((total + 7) / 8) * 8),
+  hipLaunchKernelGGL((conv_glds_kernel<BM, BN, WAVES_M, WAVES_N, STEM, VARIANT>), dim3(((total + 7) / 8) * 8),
                      dim3(WAVES_M * WAVES_N * 64), lds, st, p, ntiles, mtiles);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
@@ -721,6 +734,11 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   if (variant < 0) {
     const char *e = getenv("UOC_CONV_VARIANT");  // timing ablations of the 160x128 kernel (dev only)
     variant = e ? atoi(e) : 0;
+  }
+  if (variant >= 11 && pick_cfg(p) == 0) {  // 11..13: ablations of the LDS-DMA 160x128 kernel
+    if (variant == 11) return launch_glds<160, 128, 2, 4, false, 1>(p, st, KC_GLDS_160x128);
+    if (variant == 12) return launch_glds<160, 128, 2, 4, false, 2>(p, st, KC_GLDS_160x128);
+    return launch_glds<160, 128, 2, 4, false, 3>(p, st, KC_GLDS_160x128);
   }
   if (variant > 0 && pick_cfg(p) == 0) {
     if (variant == 1) return launch_cfg<160, 128, 2, 4, false, 1>(p, st, KC_CONV_160x128);
