@@ -319,11 +319,9 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
 #define UOC_ISSUE_ONE(KN, STG, J)                                                                              \
   if ((J) < NPASS) {                                                                                           \
     const int j = (J) < NPASS ? (J) : 0;                                                                       \
-    const int cc_ = STEM ? 0 : (KN) / T; /* K order: cin slice outer, tap inner (L2 reuse of the slice) */   \
-    const int tap = (KN)-cc_ * T;                                                                              \
-    const int c0 = cc_ * BK;                                                                                   \
-    const int kh = STEM ? tap : tap / p.KW;                                                                    \
-    const int kw = STEM ? 0 : tap - kh * p.KW;                                                                 \
+    /* K order: cin slice outer, tap inner (L2 reuse of the slice); (tap, kh, kw, c0) of chunk KN are the    \
+       running scalars q_tap.. advanced by UOC_ADVANCE (no integer divisions in the loop) */                   \
+    const int tap = q_tap, c0 = q_c0, kh = STEM ? q_tap : q_kh, kw = STEM ? 0 : q_kw;                          \
     const size_t woff = (size_t)tap * p.Cout * Kc + c0;                                                        \
     const int iy = d_iy0[j] + kh * p.dil;                                                                      \
     const int ix = d_ix0[j] + kw * p.dil;                                                                      \
@@ -362,10 +360,26 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
 #pragma unroll
     for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // running decomposition of the chunk being ISSUED: tap = kh*KW + kw within the cin slice c0
+  int q_tap = 0, q_kh = 0, q_kw = 0, q_c0 = 0;
+#define UOC_ADVANCE()              \
+  {                                \
+    ++q_tap;                       \
+    if (++q_kw == p.KW) {          \
+      q_kw = 0;                    \
+      ++q_kh;                      \
+    }                              \
+    if (q_tap == T) {              \
+      q_tap = q_kh = q_kw = 0;     \
+      q_c0 += BK;                  \
+    }                              \
+  }
   float4 wa0[TN], xb0[TM], wa1[TN], xb1[TM];
   UOC_ISSUE(0, 0)
+  UOC_ADVANCE()
   if (nk > 1) {
     UOC_ISSUE(1, 1)
+    UOC_ADVANCE()
     wait_vmcnt<NPASS>();
   } else {
     wait_vmcnt<0>();
@@ -387,30 +401,42 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
     // fragment reads +4 %; the stagger itself measured neutral, i.e. the DMA cost is not issue-slot
     // contention (suspected: L2->LDS traffic lowers the sustained clock under the power cap).
     if (kc + 2 < nk && VARIANT < 1 && early) UOC_ISSUE(kc + 2, s_nn)
-    if (VARIANT < 3) UOC_FRAG2(s_cur, 1, wa1, xb1)
+    // Fragment-read placement (checked in the ISA): hipcc sinks reads to just before their first use and
+    // its waitcnt pass is conservative across the loop back-edge (lgkmcnt(0) in front of the first MFMA
+    // of the iteration).  So: the first MFMA group runs on fragments whose reads were drained at the END
+    // of the previous iteration, the h=1 reads are issued behind it and pinned there, and every wait
+    // that can fire lands 30-40 MFMAs after the reads it covers.
     UOC_MFMA_E(wa0, xb0, x)
+    if (VARIANT < 3) UOC_FRAG2(s_cur, 1, wa1, xb1)
+    __builtin_amdgcn_sched_barrier(0);
     UOC_MFMA_E(wa0, xb0, y)
     UOC_MFMA_E(wa0, xb0, z)
     UOC_MFMA_E(wa0, xb0, w)
     if (kc + 2 < nk && VARIANT < 1 && !early) UOC_ISSUE(kc + 2, s_nn)
+    if (kc + 2 < nk) UOC_ADVANCE()
     if (VARIANT < 2) {
       if (kc + 2 < nk)
         wait_vmcnt<NPASS>();  // chunk kc+1 has landed; chunk kc+2 may still be in flight
       else
         wait_vmcnt<0>();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) as a BUILTIN so hipcc's scoreboard sees the h=1 reads retire
       __builtin_amdgcn_s_barrier();
     }
     if (kc + 1 < nk && VARIANT < 3) UOC_FRAG2(s_nxt, 0, wa0, xb0)
+    __builtin_amdgcn_sched_barrier(0);
     UOC_MFMA_E(wa1, xb1, x)
     UOC_MFMA_E(wa1, xb1, y)
     UOC_MFMA_E(wa1, xb1, z)
     UOC_MFMA_E(wa1, xb1, w)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): next chunk's h=0 fragments, issued 40 MFMAs ago
+    __builtin_amdgcn_sched_barrier(0);
     const int tmp = s_cur;
     s_cur = s_nxt;
     s_nxt = s_nn;
     s_nn = tmp;
   }
+#undef UOC_ADVANCE
 #undef UOC_ISSUE
 #undef UOC_ISSUE_ONE
 #undef UOC_FRAG2
