@@ -117,6 +117,12 @@ typedef struct uoc_roi_table {
 
 size_t uoc_roi_workspace_bytes(void);
 
+/* Input preparation (read_sample / compute_xyz, tools/test_images.py:96-133) on the device:
+ * d_bgr [H][W][3] uint8 (cv2.imread order), d_depth_mm [H][W] uint16 millimetres ->
+ * d_image [3][H][W] = bgr/255 - mean (mean_* = PIXEL_MEANS/255 as float32), d_xyz [3][H][W] metres. */
+int uoc_prep_rgbd(const uint8_t *d_bgr, const uint16_t *d_depth_mm, int H, int W, float fx, float fy, float px,
+                  float py, float mean_b, float mean_g, float mean_r, float *d_image, float *d_xyz, void *stream);
+
 /* filter_labels_depth (:183-198): per batch item, a non-zero label whose fraction of pixels with
  * z > 0 is < threshold becomes 0.  d_z: the Z plane of item 0; items are z_batch_stride floats apart. */
 int uoc_filter_labels_depth(int32_t *d_labels, const float *d_z, long z_batch_stride, int B, int H, int W,

@@ -50,3 +50,38 @@ def test_demo_frame_matches_reference(golden_dir, device):
     agree2, _ = _agreement(refined.numpy(), g["refined"])
     assert agree2 >= 0.999, agree2
     assert len(np.unique(refined.numpy())) == len(np.unique(g["refined"]))
+
+
+def test_device_input_prep_is_bit_identical(golden_dir, device):
+    """uoc_prep_rgbd (uint8 BGR + uint16 mm depth -> network inputs on the device) against the host-side
+    mirror of read_sample/compute_xyz (tools/test_images.py:96-133): same float32 ops, bit-exact."""
+    d = os.path.join(golden_dir, "demo")
+    cam = json.load(open(os.path.join(d, "camera_params.json")))
+    want = uio.read_sample(os.path.join(d, "000002-color.png"), os.path.join(d, "000002-depth.png"), cam)
+    raw = uio.read_sample_raw(os.path.join(d, "000002-color.png"), os.path.join(d, "000002-depth.png"), cam)
+    got = uio.prepare_on_device(raw, device)
+    assert torch.equal(got["image_color"].cpu(), want["image_color"])
+    assert torch.equal(got["depth"].cpu(), want["depth"])
+    # and a synthetic frame with the full uint16 range / odd size
+    rng = np.random.default_rng(5)
+    im = rng.integers(0, 256, size=(37, 53, 3), dtype=np.uint8)
+    dep = rng.integers(0, 65536, size=(37, 53)).astype(np.uint16)
+    cam2 = dict(fx=500.5, fy=499.25, x_offset=26.1, y_offset=18.7)
+    want = uio.make_sample(im, dep, cam2)
+    got = uio.prepare_on_device(uio.make_sample_raw(im, dep, cam2), device)
+    assert torch.equal(got["image_color"].cpu(), want["image_color"])
+    assert torch.equal(got["depth"].cpu(), want["depth"])
+
+
+def test_raw_sample_through_test_sample(golden_dir, device):
+    cfg.device = device
+    g = np.load(os.path.join(golden_dir, "demo.npz"))
+    d = os.path.join(golden_dir, "demo")
+    cam = json.load(open(os.path.join(d, "camera_params.json")))
+    raw = uio.read_sample_raw(os.path.join(d, "000002-color.png"), os.path.join(d, "000002-depth.png"), cam)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    net = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    np.random.seed(3)
+    out_label, refined = TD.test_sample(raw, net, net)
+    agree, _ = _agreement(out_label.numpy(), g["out_label"])
+    assert agree >= 0.999

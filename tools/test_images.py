@@ -52,7 +52,7 @@ def main():
     network_crop = networks.seg_resnet34_8s_embedding(2, cfg.TRAIN.NUM_UNITS, load_weights(args.pretrained_crop)).eval()
     outdir = args.outdir or args.imgdir
     for fc, fd in zip(colors, depths):
-        sample = uio.read_sample(fc, fd, cam)
+        sample = uio.read_sample_raw(fc, fd, cam)      # uint8/uint16 upload, prep fused on the device
         out_label, out_label_refined = test_sample(sample, network, network_crop)
         final = out_label_refined if out_label_refined is not None else out_label
         from PIL import Image

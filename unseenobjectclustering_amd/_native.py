@@ -41,6 +41,8 @@ def _declare(lib):
         getattr(lib, name).restype = c_int
     lib.uoc_roi_workspace_bytes.restype = c_size_t
     lib.uoc_roi_workspace_bytes.argtypes = []
+    lib.uoc_prep_rgbd.argtypes = [P, P, c_int, c_int] + [c_float] * 7 + [P, P, P]
+    lib.uoc_prep_rgbd.restype = c_int
     lib.uoc_filter_labels_depth.argtypes = [P, P, ctypes.c_long, c_int, c_int, c_int, c_float, P, c_size_t, P]
     lib.uoc_roi_build.argtypes = [P, P, c_int, c_int, c_float, c_float, P, P, c_size_t, P]
     lib.uoc_roi_crop.argtypes = [P, P, P, c_int, c_int, P, c_int, c_int, P, P, P, P]
@@ -64,7 +66,7 @@ EXPORTED_SYMBOLS = (
     "uoc_ms_seed_components", "uoc_ms_assign", "uoc_ms_cluster",
     "uoc_net_create", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",
     "uoc_net_forward", "uoc_conv2d_nhwc",
-    "uoc_roi_workspace_bytes", "uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats",
+    "uoc_roi_workspace_bytes", "uoc_prep_rgbd", "uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats",
     "uoc_roi_paste", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
 )
 

@@ -246,6 +246,26 @@ __global__ __launch_bounds__(256) void paste_kernel(const int *__restrict__ labe
   }
 }
 
+// Input preparation on the device (tools/test_images.py:96-133): uint8 BGR [H][W][3] + uint16 depth in
+// millimetres -> the two float NCHW tensors the path consumes.  Same float32 operations, in the same
+// order, as the reference's numpy/torch code (true divisions, no FMA contraction possible).
+__global__ __launch_bounds__(256) void prep_rgbd_kernel(const unsigned char *__restrict__ bgr,
+                                                        const unsigned short *__restrict__ depth_mm, int H, int W,
+                                                        float fx, float fy, float px, float py, float m0, float m1,
+                                                        float m2, float *__restrict__ image, float *__restrict__ xyz) {
+  const int n = H * W;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const int v = p / W, u = p - v * W;
+    image[p] = (float)bgr[3 * p + 0] / 255.0f - m0;          // im / 255.0 - PIXEL_MEANS / 255.0  (:125-127)
+    image[n + p] = (float)bgr[3 * p + 1] / 255.0f - m1;
+    image[2 * n + p] = (float)bgr[3 * p + 2] / 255.0f - m2;
+    const float z = (float)depth_mm[p] / 1000.0f;            // :113
+    xyz[p] = ((float)u - px) * z / fx;                       // :99
+    xyz[n + p] = ((float)v - py) * z / fy;                   // :100
+    xyz[2 * n + p] = z;
+  }
+}
+
 struct RoiWs {
   int *stats;  // [128][6]
   int *lut;    // [128]
@@ -282,6 +302,16 @@ using namespace uoc;
 extern "C" {
 
 size_t uoc_roi_workspace_bytes(void) { return carve_roi(nullptr).total; }
+
+int uoc_prep_rgbd(const uint8_t *d_bgr, const uint16_t *d_depth_mm, int H, int W, float fx, float fy, float px,
+                  float py, float mean_b, float mean_g, float mean_r, float *d_image, float *d_xyz, void *stream) {
+  UOC_REQUIRE(d_bgr && d_depth_mm && d_image && d_xyz, "null pointer");
+  UOC_REQUIRE(H >= 1 && W >= 1, "bad shape");
+  hipLaunchKernelGGL(prep_rgbd_kernel, dim3(grid_for(H * W)), dim3(256), 0, (hipStream_t)stream, d_bgr, d_depth_mm, H, W,
+                     fx, fy, px, py, mean_b, mean_g, mean_r, d_image, d_xyz);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
 
 int uoc_filter_labels_depth(int32_t *d_labels, const float *d_z, long z_batch_stride, int B, int H, int W,
                             float threshold, void *d_ws, size_t ws_bytes, void *stream) {

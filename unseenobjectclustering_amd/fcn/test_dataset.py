@@ -224,6 +224,9 @@ def _run_frame(sample, network, network_crop, depth_threshold, return_device=Fal
     maps on the device ([B,H,W], [1,H,W] or None) for the frame-parallel runner."""
     require_supported()
     dev = _device()
+    if "image_u8" in sample:      # raw uint8 / uint16 sample: input preparation runs on the device (io.prepare_on_device)
+        from ..io import prepare_on_device
+        sample = dict(sample, **prepare_on_device(sample, dev))
     image = sample["image_color"].to(dev).float().contiguous()
     depth = sample["depth"].to(dev).float().contiguous()
     label = sample["label"].to(dev) if "label" in sample else None
