@@ -111,3 +111,47 @@ def test_network_interface(device):
     net.train()
     with pytest.raises(NotImplementedError):
         net(torch.zeros(1, 3, 64, 64, device=device), None, torch.zeros(1, 3, 64, 64, device=device))
+
+
+WINO_CASES = [
+    # G, B, H, W, Cin, Cout, dil, residual, relu   (3x3, stride 1: the layers Winograd F(2x2,3x3) serves)
+    (1, 1, 30, 40, 64, 64, 1, True, True),
+    (2, 1, 60, 80, 128, 128, 1, False, True),
+    (2, 1, 60, 80, 256, 256, 2, True, True),
+    (2, 1, 15, 20, 512, 512, 4, True, True),      # odd phase sub-image: partial tiles
+    (1, 3, 28, 28, 256, 512, 4, False, False),    # 7x7 phase sub-images, batch 3
+    (1, 2, 13, 9, 64, 128, 2, False, True),       # ragged
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_winograd_conv_vs_torch_cpu(device, case):
+    """Winograd F(2x2,3x3) path (csrc/wino.hip) against torch CPU conv2d; fp32 Winograd differs from the
+    direct sum only by rounding (bar: 2e-4 of the output scale, measured ~1e-6)."""
+    G, B, H, W, Cin, Cout, dil, use_res, relu = case
+    g = torch.Generator().manual_seed(abs(hash(case)) % (2 ** 31))
+    x = torch.randn(G, B, Cin, H, W, generator=g)
+    w = torch.randn(G, Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(G, Cout, generator=g)
+    res = torch.randn(G, B, Cout, H, W, generator=g) if use_res else None
+    ref = torch.stack([F.conv2d(x[i], w[i], b[i], padding=dil, dilation=dil) for i in range(G)])
+    if res is not None:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    xd = x.permute(0, 1, 3, 4, 2).contiguous().to(device)
+    wd = w.permute(0, 3, 4, 1, 2).reshape(G, 9, Cout, Cin).contiguous().to(device)
+    bd = b.to(device)
+    rd = res.permute(0, 1, 3, 4, 2).contiguous().to(device) if res is not None else None
+    out = torch.empty((G, B, H, W, Cout), device=device)
+    L = _native.lib()
+    os.environ["UOC_CONV_WINOGRAD"] = "1"
+    try:
+        rc = L.uoc_conv2d_nhwc(_native.ptr(xd), _native.ptr(wd), _native.ptr(bd), _native.ptr(rd), _native.ptr(out),
+                               G, B, H, W, Cin, Cout, 3, 1, dil, dil, int(relu), _native.stream_ptr(device))
+    finally:
+        os.environ.pop("UOC_CONV_WINOGRAD", None)
+    _native.check(rc, "uoc_conv2d_nhwc (winograd)")
+    got = out.cpu().permute(0, 1, 4, 2, 3)
+    err = (got - ref).abs().max().item()
+    assert err < 2e-4 * max(1.0, ref.abs().max().item()), err

@@ -20,6 +20,13 @@ struct ConvParams {
 
 int launch_conv(const ConvParams &p, hipStream_t st);
 
+// Winograd F(2x2,3x3) path (csrc/wino.hip) for 3x3 stride-1 layers: U = transformed weights
+// [G][16][Cout][Cin] (launch_wino_weights), Vws = scratch of wino_v_floats() floats.
+bool wino_eligible(const ConvParams &p);
+size_t wino_v_floats(int G, int B, int H, int W, int d, int Cin);
+int launch_wino_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st);
+int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_t st);
+
 // NCHW [B][3][H][W] -> NHWC4 [B][H][W][4] (4th channel = 0)
 int launch_nchw3_to_nhwc4(const float *in, float *out, int B, int H, int W, hipStream_t st);
 // 3x3 s2 p1 max pooling, NHWC, C % 4 == 0; `n_img` images

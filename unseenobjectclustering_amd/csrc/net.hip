@@ -14,6 +14,8 @@
 
 #include "conv.h"
 
+#include <stdlib.h>
+
 namespace uoc {
 
 struct ConvLayer {
@@ -21,6 +23,7 @@ struct ConvLayer {
   int Cin, Cout, K, stride, dil, pad, relu;
   bool has_bn, has_bias, stem;
   float *d_w = nullptr, *d_b = nullptr;  // [G][...]
+  float *d_U = nullptr;                  // Winograd-transformed weights [G][16][Cout][Cin] (eligible layers only)
   size_t w_per_group = 0;
 };
 
@@ -37,6 +40,7 @@ struct uoc_net {
   int stem = -1, fc = -1;
   bool finalized = false;
   int device = -1;
+  int wino_min_cin = 256;  // 3x3 stride-1 layers with Cin >= this run as Winograd F(2x2,3x3); 0 = never
 };
 
 namespace uoc {
@@ -155,6 +159,15 @@ static int finalize_layer(uoc_net *n, ConvLayer &L) {
   UOC_HIP_CHECK(hipMalloc(&L.d_b, hb.size() * sizeof(float)));
   UOC_HIP_CHECK(hipMemcpy(L.d_w, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice));
   UOC_HIP_CHECK(hipMemcpy(L.d_b, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+  // Measured on MI355X (scripts/conv_microbench.py): Winograd wins from 256 input channels up
+  // (layer4 1.4x, layer3 1.0-1.2x) and loses below (the transforms dominate), hence the static rule.
+  // Static, not autotuned: the two algorithms round differently, and results must not depend on timing.
+  if (!L.stem && L.K == 3 && L.stride == 1 && n->wino_min_cin > 0 && L.Cin >= n->wino_min_cin && L.Cin % 32 == 0 &&
+      L.Cout % 64 == 0) {
+    UOC_HIP_CHECK(hipMalloc(&L.d_U, (size_t)G * 16 * L.Cout * L.Cin * sizeof(float)));
+    if (int rc = launch_wino_weights(L.d_w, L.d_U, G, L.Cout, L.Cin, nullptr)) return rc;
+    UOC_HIP_CHECK(hipDeviceSynchronize());
+  }
   return UOC_OK;
 }
 
@@ -173,7 +186,7 @@ static Dims dims(int H, int W) {
 }
 
 struct NetWs {
-  float *in4, *stem, *buf[4], *fc;
+  float *in4, *stem, *buf[4], *fc, *wino;
   size_t total;
 };
 static NetWs carve_net(void *base, int B, int H, int W) {
@@ -192,12 +205,21 @@ static NetWs carve_net(void *base, int B, int H, int W) {
   if (a3 > act) act = a3;
   for (int i = 0; i < 4; ++i) w.buf[i] = take(act);
   w.fc = take((size_t)G * B * d.H3 * d.W3 * 64);
+  // Winograd scratch V[G][16][tiles][Cin]: worst case over the layers that may use it (1/8 resolution,
+  // dilation 2 with 256 channels or dilation 4 with 512 channels; also sized for 1/4 resolution x 64)
+  size_t wv = wino_v_floats(G, B, d.H3, d.W3, 4, 512);
+  const size_t wv3 = wino_v_floats(G, B, d.H3, d.W3, 2, 256), wv2 = wino_v_floats(G, B, d.H3, d.W3, 1, 128),
+               wv1 = wino_v_floats(G, B, d.H2, d.W2, 1, 64);
+  if (wv3 > wv) wv = wv3;
+  if (wv2 > wv) wv = wv2;
+  if (wv1 > wv) wv = wv1;
+  w.wino = take(wv);
   w.total = off;
   return w;
 }
 
 static int run_conv(const ConvLayer &L, const float *in, const float *res, float *out, int B, int H, int W, int Ho,
-                    int Wo, hipStream_t st) {
+                    int Wo, hipStream_t st, float *wino_ws = nullptr) {
   ConvParams p;
   p.in = in;
   p.w = L.d_w;
@@ -218,6 +240,7 @@ static int run_conv(const ConvLayer &L, const float *in, const float *res, float
   p.pad = L.pad;
   p.relu = L.relu;
   p.stem = L.stem ? 1 : 0;
+  if (L.d_U && wino_ws && wino_eligible(p)) return launch_wino_conv(p, L.d_U, wino_ws, st);
   return launch_conv(p, st);
 }
 
@@ -235,6 +258,7 @@ int uoc_net_create(uoc_net **out) {
     return UOC_ENOMEM;
   }
   build_graph(n);
+  if (const char *e = getenv("UOC_WINOGRAD_MIN_CIN")) n->wino_min_cin = atoi(e);  // 0 disables the Winograd path
   *out = n;
   return UOC_OK;
 }
@@ -244,6 +268,7 @@ int uoc_net_destroy(uoc_net *n) {
   for (auto &L : n->layers) {
     if (L.d_w) (void)hipFree(L.d_w);
     if (L.d_b) (void)hipFree(L.d_b);
+    if (L.d_U) (void)hipFree(L.d_U);
   }
   delete n;
   return UOC_OK;
@@ -295,13 +320,13 @@ int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, i
     const ConvLayer &c1 = n->layers[b.conv1], &c2 = n->layers[b.conv2];
     const int ho = (h - 1) / c1.stride + 1, wo = (wd - 1) / c1.stride + 1;
     float *x = w.buf[cur], *tmp = w.buf[(cur + 1) & 3], *sc = w.buf[(cur + 2) & 3], *y = w.buf[(cur + 3) & 3];
-    if (int rc = run_conv(c1, x, nullptr, tmp, B, h, wd, ho, wo, st)) return rc;
+    if (int rc = run_conv(c1, x, nullptr, tmp, B, h, wd, ho, wo, st, w.wino)) return rc;
     const float *res = x;
     if (b.down >= 0) {
       if (int rc = run_conv(n->layers[b.down], x, nullptr, sc, B, h, wd, ho, wo, st)) return rc;
       res = sc;
     }
-    if (int rc = run_conv(c2, tmp, res, y, B, ho, wo, ho, wo, st)) return rc;
+    if (int rc = run_conv(c2, tmp, res, y, B, ho, wo, ho, wo, st, w.wino)) return rc;
     cur = (cur + 3) & 3;
     h = ho;
     wd = wo;
@@ -336,6 +361,31 @@ int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, co
   p.stem = 0;
   p.Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   p.Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
+  const char *force = getenv("UOC_CONV_WINOGRAD");  // test / micro-benchmark hook: 1 = Winograd for eligible shapes
+  if (force && atoi(force) == 1 && wino_eligible(p)) {
+    // scratch owned by this entry (kept between calls; the network path gets its scratch from the caller)
+    static float *U = nullptr, *V = nullptr;
+    static size_t ucap = 0, vcap = 0;
+    static const float *u_for = nullptr;
+    const size_t un = (size_t)G * 16 * Cout * Cin, vn = wino_v_floats(G, B, H, W, dil, Cin);
+    hipStream_t st = (hipStream_t)stream;
+    if (un > ucap) {
+      if (U) (void)hipFree(U);
+      UOC_HIP_CHECK(hipMalloc(&U, un * sizeof(float)));
+      ucap = un;
+      u_for = nullptr;
+    }
+    if (vn > vcap) {
+      if (V) (void)hipFree(V);
+      UOC_HIP_CHECK(hipMalloc(&V, vn * sizeof(float)));
+      vcap = vn;
+    }
+    if (u_for != d_w) {
+      if (int rc = launch_wino_weights(d_w, U, G, Cout, Cin, st)) return rc;
+      u_for = d_w;
+    }
+    return launch_wino_conv(p, U, V, st);
+  }
   return launch_conv(p, (hipStream_t)stream);
 }
 

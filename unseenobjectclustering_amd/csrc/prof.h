@@ -17,6 +17,8 @@ enum KernelClass {
   KC_GLDS_80x128,
   KC_GLDS_160x64,
   KC_GLDS_80x64,
+  KC_WINO_INPUT,
+  KC_WINO_GEMM,
   KC_NET_MISC,  // layout conversion, max-pool
   KC_HEAD,
   KC_FPS_STEP,

@@ -14,6 +14,7 @@ bool g_prof_enabled = false;
 static const char *kNames[KC_COUNT] = {
     "conv_mfma_160x128", "conv_mfma_80x128", "conv_mfma_160x64", "conv_mfma_80x64", "conv_stem",
     "conv_glds_160x128", "conv_glds_80x128", "conv_glds_160x64", "conv_glds_80x64",
+    "wino_input",        "wino_gemm",
     "net_misc",          "head",             "fps_step",         "hc_iter",         "hc_finalize",
     "seed_cc",           "assign",           "relabel",          "roi"};
 

@@ -1,0 +1,452 @@
+// Winograd F(2x2, 3x3) convolution for the 3x3 stride-1 (possibly dilated) layers of the backbone:
+// 2.25x fewer matrix-core flops than the direct implicit GEMM, still exact-fp32 MFMA arithmetic.
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A          per 2x2 output tile, 4x4 input patch, 16 "frequencies"
+//
+// Dilation d is handled by phase decomposition: outputs of one phase (y mod d, x mod d) depend only on
+// inputs of the same phase, so a tile covers outputs (oy, ox) + {0,d}x{0,d} and its patch the inputs
+// (oy, ox) + {-d,0,d,2d}^2; zero padding is the out-of-range zero fill of the patch.
+//
+// Three kernels (csrc/net.hip decides per layer; results differ from the direct kernel only by fp32
+// rounding, ~1e-6 relative):
+//   wino_weight_kernel  U[g][xi][cout][cin] = G g G^T           once, at uoc_net_finalize
+//   wino_input_kernel   V[g][xi][tile][cin] = B^T d B           elementwise, NHWC float4
+//   wino_gemm_kernel    M_xi = U_xi V_xi^T on v_mfma_f32_16x16x4_f32, the OUTPUT transform folded in:
+//     8 waves = 2 frequency groups (xi 0-7 / 8-15) x 4 groups of 16 output channels; a group walks its
+//     8 frequencies one after the other (K order: frequency outer, cin inner), and after the last cin
+//     chunk of a frequency folds M_xi into the four 2x2-output accumulators with the +-1/0 coefficients
+//     of A^T (.) A^T.  The two groups' partial outputs meet once in LDS; bias, residual and ReLU are
+//     applied in the epilogue.  Operand staging is the LDS-DMA ring of csrc/conv.hip (3 stages, two
+//     chunks ahead, counted vmcnt, source-side XOR swizzle, zero page).
+#include "conv.h"
+#include "prof.h"
+
+#include <stdlib.h>
+
+namespace uoc {
+
+constexpr int WBK = 32;  // cin chunk
+constexpr int WBN = 64;  // output channels per block
+
+struct WinoGeom {
+  int B, H, W, d, TH, TW, NT;  // TH x TW tiles per (image, phase); NT = B*d*d*TH*TW
+};
+
+static WinoGeom make_geom(int B, int H, int W, int d) {
+  WinoGeom g;
+  g.B = B;
+  g.H = H;
+  g.W = W;
+  g.d = d;
+  g.TH = ((H + d - 1) / d + 1) / 2;
+  g.TW = ((W + d - 1) / d + 1) / 2;
+  g.NT = B * d * d * g.TH * g.TW;
+  return g;
+}
+
+__device__ __forceinline__ void wino_decode(int tau, const WinoGeom &g, int &b, int &oy, int &ox) {
+  const int tx = tau % g.TW;
+  tau /= g.TW;
+  const int ty = tau % g.TH;
+  tau /= g.TH;
+  const int px = tau % g.d;
+  tau /= g.d;
+  const int py = tau % g.d;
+  b = tau / g.d;
+  oy = py + 2 * ty * g.d;
+  ox = px + 2 * tx * g.d;
+}
+
+// ---- weights: U = G g G^T,  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]] ---------------------------
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int G,
+                                                          int Cout, int Cin) {
+  const long total = (long)G * Cout * Cin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int co = (int)((i / Cin) % Cout);
+    const int g = (int)(i / ((long)Cin * Cout));
+    float k[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) k[a][b] = w[(((size_t)g * 9 + a * 3 + b) * Cout + co) * Cin + ci];
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      t[0][b] = k[0][b];
+      t[1][b] = 0.5f * (k[0][b] + k[1][b] + k[2][b]);
+      t[2][b] = 0.5f * (k[0][b] - k[1][b] + k[2][b]);
+      t[3][b] = k[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const float u0 = t[a][0];
+      const float u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+      const float u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+      const float u3 = t[a][2];
+      const size_t o = (((size_t)g * 16 + a * 4) * Cout + co) * Cin + ci;
+      const size_t s = (size_t)Cout * Cin;
+      U[o] = u0;
+      U[o + s] = u1;
+      U[o + 2 * s] = u2;
+      U[o + 3 * s] = u3;
+    }
+  }
+}
+
+// ---- input: V = B^T d B,  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]] --------------------------
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+__global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ in, float *__restrict__ V,
+                                                         WinoGeom geo, int G, int C) {
+  const int C4 = C >> 2;
+  const long total = (long)G * geo.NT * C4;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(idx % C4);
+    const int tau = (int)((idx / C4) % geo.NT);
+    const int g = (int)(idx / ((long)C4 * geo.NT));
+    int b, oy, ox;
+    wino_decode(tau, geo, b, oy, ox);
+    const float *src = in + (((size_t)g * geo.B + b) * geo.H * geo.W) * C + 4 * c4;
+    float4 dd[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int y = oy + (i - 1) * geo.d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int x = ox + (j - 1) * geo.d;
+        const bool ok = (unsigned)y < (unsigned)geo.H && (unsigned)x < (unsigned)geo.W;
+        dd[i][j] = ok ? *reinterpret_cast<const float4 *>(src + ((size_t)y * geo.W + x) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float4 t[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      t[0][j] = f4sub(dd[0][j], dd[2][j]);
+      t[1][j] = f4add(dd[1][j], dd[2][j]);
+      t[2][j] = f4sub(dd[2][j], dd[1][j]);
+      t[3][j] = f4sub(dd[1][j], dd[3][j]);
+    }
+    const size_t plane = (size_t)geo.NT * C;
+    float *dst = V + ((size_t)g * 16 * geo.NT + tau) * C + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<float4 *>(dst + (size_t)(4 * i + 0) * plane) = f4sub(t[i][0], t[i][2]);
+      *reinterpret_cast<float4 *>(dst + (size_t)(4 * i + 1) * plane) = f4add(t[i][1], t[i][2]);
+      *reinterpret_cast<float4 *>(dst + (size_t)(4 * i + 2) * plane) = f4sub(t[i][2], t[i][1]);
+      *reinterpret_cast<float4 *>(dst + (size_t)(4 * i + 3) * plane) = f4sub(t[i][1], t[i][3]);
+    }
+  }
+}
+
+// ---- GEMM over the 16 frequencies with the output transform folded in -----------------------------
+__device__ float4 g_wino_zero[8];  // zero page for tile rows beyond NT
+
+// A^T (.) A^T coefficients: cY[xi = 4i+j][k = 2a+b] = At[a][i] * At[b][j],  At = [[1,1,1,0],[0,1,-1,-1]]
+__constant__ float c_wino_y[16][4] = {
+    {1, 0, 0, 0},  {1, 1, 0, 0},   {1, -1, 0, 0},  {0, -1, 0, 0},   // i = 0
+    {1, 0, 1, 0},  {1, 1, 1, 1},   {1, -1, 1, -1}, {0, -1, 0, -1},  // i = 1
+    {1, 0, -1, 0}, {1, 1, -1, -1}, {1, -1, -1, 1}, {0, -1, 0, 1},   // i = 2
+    {0, 0, -1, 0}, {0, 0, -1, -1}, {0, 0, -1, 1},  {0, 0, 0, 1},    // i = 3
+};
+
+__device__ __forceinline__ void wglds16(const float *g, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(g), "s"(lds_dst)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wwait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ f32x4 wmfma(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int TMT>
+__global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
+                                                        const float *__restrict__ bias_, const float *__restrict__ res_,
+                                                        float *__restrict__ out_, WinoGeom geo, int G, int Cin, int Cout,
+                                                        int relu, int ntiles, int mtiles) {
+  constexpr int BM = 16 * TMT;      // winograd tiles per block
+  constexpr int SEG = BM + WBN;     // rows of one frequency group in a stage: V rows, then U rows
+  constexpr int R = 2 * SEG;        // two groups work on two different frequencies at once
+  constexpr int RPP = 64;           // 8 waves x 8 rows per DMA pass
+  constexpr int NPASS = (R + RPP - 1) / RPP;
+  constexpr int STAGE = R * WBK;
+  static_assert(SEG % 16 == 0 && NPASS <= 8, "tile shape");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int total = G * ntiles * mtiles;
+  const int per_xcd = (total + 7) >> 3;
+  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (work >= total) return;
+  const int g = work / (ntiles * mtiles);
+  const int rem = work - g * (ntiles * mtiles);
+  const int nt = rem / mtiles, mt = rem - nt * mtiles;
+  const int m0 = mt * BM, n0 = nt * WBN;
+  const int NT = geo.NT;
+  const int cpt = Cin / WBK;
+  const int nit = 8 * cpt;
+
+  const float *zero = reinterpret_cast<const float *>(g_wino_zero);
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char *)smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int f = wave >> 2, wn = wave & 3;  // frequency group, 16-cout group
+  const int t = lane & 15, q = lane >> 4;
+
+  // ---- DMA descriptors ---------------------------------------------------------------------------
+  int d_r0[NPASS], d_off[NPASS], d_kind[NPASS];  // kind: bit0 = U row, bit1 = frequency group, 4 = zero page
+#pragma unroll
+  for (int j = 0; j < NPASS; ++j) {
+    int r0 = j * RPP + wave * 8;
+    if (r0 >= R) r0 = R - 8;
+    d_r0[j] = r0;
+    const int r = r0 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int fr = r >= SEG ? 1 : 0;
+    const int rr = r - fr * SEG;
+    if (rr >= BM) {
+      d_kind[j] = 1 | (fr << 1);
+      d_off[j] = (n0 + rr - BM) * Cin + 4 * c;
+    } else {
+      const int tau = m0 + rr;
+      d_kind[j] = (tau < NT) ? (fr << 1) : 4;
+      d_off[j] = tau * Cin + 4 * c;
+    }
+  }
+  // running (frequency-pair e, cin offset c0) of the chunk being issued
+  int q_e = 0, q_c0 = 0;
+#define W_ISSUE(STG)                                                                                    \
+  {                                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                                 \
+      const int kd = d_kind[j];                                                                         \
+      const int xi = ((kd >> 1) & 1) * 8 + q_e;                                                         \
+      const size_t plane = (size_t)(g * 16 + xi);                                                       \
+      const unsigned long long au = (unsigned long long)(U + plane * Cout * Cin + q_c0 + d_off[j]);     \
+      const unsigned long long av = (unsigned long long)(V + plane * NT * Cin + q_c0 + d_off[j]);       \
+      const unsigned long long src = (kd & 4) ? (unsigned long long)zero : ((kd & 1) ? au : av);        \
+      wglds16(reinterpret_cast<const float *>(src),                                                     \
+              lds_base + (unsigned)(((STG)*STAGE + d_r0[j] * WBK) * sizeof(float)));                    \
+    }                                                                                                   \
+  }
+#define W_ADVANCE()          \
+  {                          \
+    q_c0 += WBK;             \
+    if (q_c0 == Cin) {       \
+      q_c0 = 0;              \
+      ++q_e;                 \
+    }                        \
+  }
+#define W_FRAG(STG, HH, WA, XB)                                                                            \
+  {                                                                                                        \
+    const float *base_ = smem + (STG)*STAGE + f * SEG * WBK;                                               \
+    const int slot_ = ((4 * (HH) + q) ^ ((t >> 1) & 7)) * 4;                                               \
+    WA = *reinterpret_cast<const float4 *>(base_ + (BM + wn * 16 + t) * WBK + slot_);                      \
+    _Pragma("unroll") for (int i = 0; i < TMT; ++i) XB[i] =                                                \
+        *reinterpret_cast<const float4 *>(base_ + (16 * i + t) * WBK + slot_);                             \
+  }
+#define W_MFMA_E(WA, XB, E) \
+  { _Pragma("unroll") for (int i = 0; i < TMT; ++i) M[i] = wmfma(WA.E, XB[i].E, M[i]); }
+
+  f32x4 M[TMT], Y[4][TMT];
+#pragma unroll
+  for (int i = 0; i < TMT; ++i) {
+    M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Y[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  float4 wa0, wa1, xb0[TMT], xb1[TMT];
+  W_ISSUE(0)
+  W_ADVANCE()
+  if (nit > 1) {
+    W_ISSUE(1)
+    W_ADVANCE()
+    wwait_vmcnt<NPASS>();
+  } else {
+    wwait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  W_FRAG(0, 0, wa0, xb0)
+  int s_cur = 0, s_nxt = 1, s_nn = 2;
+  int cc = 0, e_cur = 0;  // cin chunk / frequency-pair of the chunk being multiplied
+  const bool early = wave < 4;
+  for (int it = 0; it < nit; ++it) {
+    if (it + 2 < nit && early) W_ISSUE(s_nn)
+    W_MFMA_E(wa0, xb0, x)
+    W_FRAG(s_cur, 1, wa1, xb1)
+    __builtin_amdgcn_sched_barrier(0);
+    W_MFMA_E(wa0, xb0, y)
+    W_MFMA_E(wa0, xb0, z)
+    W_MFMA_E(wa0, xb0, w)
+    if (it + 2 < nit && !early) W_ISSUE(s_nn)
+    if (it + 2 < nit) W_ADVANCE()
+    if (it + 2 < nit)
+      wwait_vmcnt<NPASS>();
+    else
+      wwait_vmcnt<0>();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    if (it + 1 < nit) W_FRAG(s_nxt, 0, wa0, xb0)
+    __builtin_amdgcn_sched_barrier(0);
+    W_MFMA_E(wa1, xb1, x)
+    W_MFMA_E(wa1, xb1, y)
+    W_MFMA_E(wa1, xb1, z)
+    W_MFMA_E(wa1, xb1, w)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+    if (++cc == cpt) {  // frequency xi = 8f + e_cur is complete: fold it into the four output accumulators
+      cc = 0;
+      const int xi = 8 * f + e_cur;
+      ++e_cur;
+      const float c0 = c_wino_y[xi][0], c1 = c_wino_y[xi][1], c2 = c_wino_y[xi][2], c3 = c_wino_y[xi][3];
+#pragma unroll
+      for (int i = 0; i < TMT; ++i) {
+        Y[0][i] += c0 * M[i];
+        Y[1][i] += c1 * M[i];
+        Y[2][i] += c2 * M[i];
+        Y[3][i] += c3 * M[i];
+        M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const int tmp = s_cur;
+    s_cur = s_nxt;
+    s_nxt = s_nn;
+    s_nn = tmp;
+  }
+#undef W_ISSUE
+#undef W_ADVANCE
+#undef W_FRAG
+#undef W_MFMA_E
+
+  // ---- the two frequency groups meet in LDS; group 0 writes the 2x2 outputs ---------------------------
+  f32x4 *red = reinterpret_cast<f32x4 *>(smem);  // [wn][k][i][lane]
+  __syncthreads();
+  if (f == 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < TMT; ++i) red[((wn * 4 + k) * TMT + i) * 64 + lane] = Y[k][i];
+  }
+  __syncthreads();
+  if (f == 0) {
+    const size_t gsz = (size_t)geo.B * geo.H * geo.W * Cout;
+    const float *bias = bias_ + (size_t)g * Cout;
+    const float *res = res_ ? res_ + (size_t)g * gsz : nullptr;
+    float *out = out_ + (size_t)g * gsz;
+    const int co = n0 + wn * 16 + 4 * q;
+    const float4 bv = *reinterpret_cast<const float4 *>(bias + co);
+#pragma unroll
+    for (int i = 0; i < TMT; ++i) {
+      const int tau = m0 + 16 * i + t;
+      if (tau >= NT) continue;
+      int b, oy, ox;
+      wino_decode(tau, geo, b, oy, ox);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const f32x4 yv = Y[k][i] + red[((wn * 4 + k) * TMT + i) * 64 + lane];
+        const int y = oy + (k >> 1) * geo.d, x = ox + (k & 1) * geo.d;
+        if (y < geo.H && x < geo.W) {
+          const size_t o = (((size_t)b * geo.H + y) * geo.W + x) * Cout + co;
+          float4 v = make_float4(yv[0] + bv.x, yv[1] + bv.y, yv[2] + bv.z, yv[3] + bv.w);
+          if (res) {
+            const float4 rv = *reinterpret_cast<const float4 *>(res + o);
+            v.x += rv.x;
+            v.y += rv.y;
+            v.z += rv.z;
+            v.w += rv.w;
+          }
+          if (relu) {
+            v.x = fmaxf(v.x, 0.f);
+            v.y = fmaxf(v.y, 0.f);
+            v.z = fmaxf(v.z, 0.f);
+            v.w = fmaxf(v.w, 0.f);
+          }
+          *reinterpret_cast<float4 *>(out + o) = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TMT>
+static int launch_wino_gemm(const ConvParams &p, const float *U, const float *V, const WinoGeom &geo, hipStream_t st) {
+  constexpr int BM = 16 * TMT;
+  const int mtiles = (geo.NT + BM - 1) / BM, ntiles = p.Cout / WBN;
+  const size_t lds = (size_t)3 * 2 * (BM + WBN) * WBK * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_gemm_kernel<TMT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int total = mtiles * ntiles * p.G;
+  hipLaunchKernelGGL((wino_gemm_kernel<TMT>), dim3(((total + 7) / 8) * 8), dim3(512), lds, st, V, U, p.bias, p.res, p.out,
+                     geo, p.G, p.Cin, p.Cout, p.relu, ntiles, mtiles);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+bool wino_eligible(const ConvParams &p) {
+  return !p.stem && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && p.Cin % WBK == 0 && p.Cout % WBN == 0 &&
+         p.Ho == p.H && p.Wo == p.W;
+}
+
+size_t wino_v_floats(int G, int B, int H, int W, int d, int Cin) {
+  const WinoGeom geo = make_geom(B, H, W, d);
+  return (size_t)G * 16 * geo.NT * Cin;
+}
+
+int launch_wino_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st) {
+  const long total = (long)G * Cout * Cin;
+  long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w, U, G, Cout, Cin);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_t st) {
+  UOC_REQUIRE(wino_eligible(p), "winograd: layer not eligible");
+  UOC_REQUIRE(U && Vws, "winograd: null weight/workspace pointer");
+  const WinoGeom geo = make_geom(p.B, p.H, p.W, p.dil);
+  {
+    ProfScope prof(KC_WINO_INPUT, st, 0.0, 4.0 * p.G * ((double)p.B * p.H * p.W * p.Cin + 16.0 * geo.NT * p.Cin));
+    const long total = (long)p.G * geo.NT * (p.Cin / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.in, Vws, geo, p.G, p.Cin);
+  }
+  // pixel-tile height: whole rounds of 256 CUs, mild preference for tall tiles
+  const int ntiles = p.Cout / WBN;
+  int best = 5;
+  double best_cost = -1;
+  for (int tmt = 4; tmt <= 7; ++tmt) {
+    const long blocks = (long)((geo.NT + 16 * tmt - 1) / (16 * tmt)) * ntiles * p.G;
+    const long rounds = (blocks + 255) / 256;
+    const double cost = (double)rounds * tmt * (1.0 + 0.04 * (7.0 / tmt - 1.0));
+    if (best_cost < 0 || cost <= best_cost) {
+      best = tmt;
+      best_cost = cost;
+    }
+  }
+  const double M = (double)p.B * p.H * p.W;
+  ProfScope prof(KC_WINO_GEMM, st, 2.0 * M * p.Cout * p.Cin * 9.0 * p.G,
+                 4.0 * p.G * (16.0 * geo.NT * p.Cin + 16.0 * p.Cout * p.Cin + M * p.Cout * (p.res ? 2 : 1)));
+  switch (best) {
+    case 4: return launch_wino_gemm<4>(p, U, Vws, geo, st);
+    case 6: return launch_wino_gemm<6>(p, U, Vws, geo, st);
+    case 7: return launch_wino_gemm<7>(p, U, Vws, geo, st);
+    default: return launch_wino_gemm<5>(p, U, Vws, geo, st);
+  }
+}
+
+}  // namespace uoc
