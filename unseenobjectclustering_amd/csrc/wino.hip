@@ -225,15 +225,16 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
   int q_e = 0, q_c0 = 0;
 #define W_ISSUE(STG)                                                                                    \
   {                                                                                                     \
+    /* four wave-uniform row bases (U / V plane of each frequency group) for this chunk; the per-lane  \
+       part of an address is a select + a 32-bit offset add */                                          \
+    const size_t pl0_ = (size_t)(g * 16 + q_e), pl1_ = pl0_ + 8;                                        \
+    const float *bu0_ = U + pl0_ * Cout * Cin + q_c0, *bu1_ = U + pl1_ * Cout * Cin + q_c0;             \
+    const float *bv0_ = V + pl0_ * NT * Cin + q_c0, *bv1_ = V + pl1_ * NT * Cin + q_c0;                 \
     _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                                 \
       const int kd = d_kind[j];                                                                         \
-      const int xi = ((kd >> 1) & 1) * 8 + q_e;                                                         \
-      const size_t plane = (size_t)(g * 16 + xi);                                                       \
-      const unsigned long long au = (unsigned long long)(U + plane * Cout * Cin + q_c0 + d_off[j]);     \
-      const unsigned long long av = (unsigned long long)(V + plane * NT * Cin + q_c0 + d_off[j]);       \
-      const unsigned long long src = (kd & 4) ? (unsigned long long)zero : ((kd & 1) ? au : av);        \
-      wglds16(reinterpret_cast<const float *>(src),                                                     \
-              lds_base + (unsigned)(((STG)*STAGE + d_r0[j] * WBK) * sizeof(float)));                    \
+      const float *b_ = (kd & 1) ? ((kd & 2) ? bu1_ : bu0_) : ((kd & 2) ? bv1_ : bv0_);                 \
+      const float *src = (kd & 4) ? zero : b_ + d_off[j];                                               \
+      wglds16(src, lds_base + (unsigned)(((STG)*STAGE + d_r0[j] * WBK) * sizeof(float)));               \
     }                                                                                                   \
   }
 #define W_ADVANCE()          \
