@@ -195,11 +195,15 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom["kernel"])
-        if dom["kernel"].startswith("conv") or dom["kernel"] in ("hc_iter", "assign"):   # MFMA-bound classes
+        if dom["kernel"].startswith(("conv", "wino_gemm")) or dom["kernel"] in ("hc_iter", "assign"):   # MFMA-bound classes
             ach = dom["flops"] / sec / 1e12
             roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2)}
+            if dom["kernel"] == "wino_gemm":
+                # `achieved` counts the ALGORITHMIC (direct 3x3) flops; Winograd F(2x2,3x3) executes 16/36 of them
+                roof["executed_tflops"] = round(ach * 16.0 / 36.0, 2)
+                roof["note"] = "algorithmic flops of the direct 3x3 conv; Winograd executes 16/36 of them on the MFMA pipe"
         else:
             ach = dom["bytes"] / sec / 1e9
             roof = {"kernel": dom["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
