@@ -83,7 +83,16 @@ int uoc_ms_cluster(const float *d_X, int batch, int n, int m, float kappa, int i
  * ---------------------------------------------------------------------------------------- */
 typedef struct uoc_net uoc_net;
 
-int uoc_net_create(uoc_net **out);
+/* Input modality / fusion of SEGNET (SEG.py:69-71 construction, :97-110 forward):
+ *   RGBD_ADD   cfg.INPUT='RGBD', FUSION_TYPE='add'   : fcn(img) + fcn_depth(xyz)          (two backbones)
+ *   COLOR      cfg.INPUT='COLOR'                     : fcn(img)
+ *   DEPTH      cfg.INPUT='DEPTH'                     : fcn(xyz)   (the weights still live under "fcn.")
+ *   RGBD_EARLY cfg.INPUT='RGBD', FUSION_TYPE='early' : fcn(cat(img, xyz)), a 6-channel stem (SEG.py:178-181)
+ * FUSION_TYPE='cat' (128-d embeddings) is not implemented. */
+enum { UOC_NET_RGBD_ADD = 0, UOC_NET_COLOR = 1, UOC_NET_DEPTH = 2, UOC_NET_RGBD_EARLY = 3 };
+
+int uoc_net_create(uoc_net **out);                   /* = uoc_net_create_mode(out, UOC_NET_RGBD_ADD) */
+int uoc_net_create_mode(uoc_net **out, int mode);
 int uoc_net_destroy(uoc_net *net);
 /* One state-dict entry by its reference key ("fcn.resnet34_8s.layer1.0.conv1.weight", ...;
  * SEG.py:130-159 contract), HOST fp32 memory, copied. */
@@ -93,6 +102,7 @@ int uoc_net_load_param(uoc_net *net, const char *name, const float *host_data, s
 int uoc_net_finalize(uoc_net *net);
 size_t uoc_net_workspace_bytes(const uoc_net *net, int B, int H, int W);
 /* d_rgb, d_xyz: [B][3][H][W] fp32 NCHW (what test_sample hands the network, test_dataset.py:247);
+ * the one the mode does not read (d_xyz for COLOR, d_rgb for DEPTH) may be NULL.
  * d_embed: [B][H*W][64] pixel-major unit-norm embeddings. */
 int uoc_net_forward(uoc_net *net, const float *d_rgb, const float *d_xyz, int B, int H, int W, float *d_embed,
                     void *d_ws, size_t ws_bytes, void *stream);
@@ -134,13 +144,15 @@ int uoc_roi_build(int32_t *d_labels, const float *d_z, int H, int W, float thres
                   uoc_roi_table *d_table, void *d_ws, size_t ws_bytes, void *stream);
 
 /* crop_rois (:95-110): crops of the [3][H][W] image / XYZ planes resized to SxS with bilinear
- * align_corners=True, object mask with nearest.  Outputs NCHW [K][3][S][S] and [K][S][S]. */
+ * align_corners=True, object mask with nearest.  Outputs NCHW [K][3][S][S] and [K][S][S].
+ * COLOR input (depth is None, :73-76): d_xyz = d_xyz_crops = NULL. */
 int uoc_roi_crop(const float *d_rgb, const float *d_xyz, const int32_t *d_labels, int H, int W,
                  const uoc_roi_table *d_table, int K, int S, float *d_rgb_crops, float *d_xyz_crops,
                  float *d_mask_crops, void *stream);
 
 /* match_label_crop part 1 (:118-136): d_keep[k][c] = 1 iff crop cluster c of ROI k overlaps the
- * stage-1 mask by >= 50 %; d_meanz[k] = mean z (>0) over kept pixels (all pixels if none kept). */
+ * stage-1 mask by >= 50 %; d_meanz[k] = mean z (>0) over kept pixels (all pixels if none kept).
+ * Without depth (d_xyz_crops = NULL) d_meanz is not written: ROIs are ordered by box area (:138-146). */
 int uoc_roi_match_stats(const int32_t *d_labels_crop, const float *d_mask_crops, const float *d_xyz_crops, int K,
                         int S, int32_t *d_keep, float *d_meanz, void *d_ws, size_t ws_bytes, void *stream);
 

@@ -2,9 +2,9 @@
 ResNet34-8s embedding forward pass with plain torch CPU ops, driven by a flat state dict.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
-Pinned against the reference's own SEGNET.forward by tests/golden/backbone.npz.
+Pinned against the reference's own SEGNET.forward by tests/golden/backbone.npz and modes.npz.
 
-Reference: lib/networks/SEG.py:88-119 (RGBD 'add'), lib/networks/resnet_dilated.py:287-327,
+Reference: lib/networks/SEG.py:88-119 (RGBD 'add' / 'early', COLOR, DEPTH), lib/networks/resnet_dilated.py:287-327,
 lib/networks/resnet.py:116-270.
 """
 from __future__ import annotations
@@ -58,9 +58,20 @@ def resnet34_8s(sd, pfx, x):
     return x, up
 
 
-def segnet_forward(sd, img, depth):
-    """normalize(fcn(img) + fcn_depth(depth)) -> [B,64,H,W]  (SEG.py:105-108,113-114)."""
+def segnet_forward(sd, img, depth, mode="RGBD_ADD"):
+    """SEG.py:97-114 -> [B,64,H,W] unit-norm.  mode: 'RGBD_ADD' normalize(fcn(img) + fcn_depth(depth)) (:106-108),
+    'COLOR' fcn(img) (:100), 'DEPTH' fcn(depth) (:98), 'RGBD_EARLY' fcn(cat(img, depth)) (:102-103)."""
     with torch.no_grad():
-        _, a = resnet34_8s(sd, "fcn.resnet34_8s.", img)
-        _, b = resnet34_8s(sd, "fcn_depth.resnet34_8s.", depth)
-        return F.normalize(a + b, p=2, dim=1)
+        if mode == "RGBD_ADD":
+            _, a = resnet34_8s(sd, "fcn.resnet34_8s.", img)
+            _, b = resnet34_8s(sd, "fcn_depth.resnet34_8s.", depth)
+            a = a + b
+        elif mode == "COLOR":
+            _, a = resnet34_8s(sd, "fcn.resnet34_8s.", img)
+        elif mode == "DEPTH":
+            _, a = resnet34_8s(sd, "fcn.resnet34_8s.", depth)
+        elif mode == "RGBD_EARLY":
+            _, a = resnet34_8s(sd, "fcn.resnet34_8s.", torch.cat((img, depth), 1))
+        else:
+            raise ValueError(mode)
+        return F.normalize(a, p=2, dim=1)

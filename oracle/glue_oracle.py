@@ -58,13 +58,14 @@ def crop_rois(rgb: torch.Tensor, initial_masks: torch.Tensor, depth: torch.Tenso
     K = len(ids)
     S = crop_size
     rgb_crops = torch.zeros((K, 3, S, S))
-    depth_crops = torch.zeros((K, 3, S, S))
+    depth_crops = torch.zeros((K, 3, S, S)) if depth is not None else None        # :73-76
     mask_crops = torch.zeros((K, S, S))
     for k, mid in enumerate(ids):
         x0, y0, x1, y1 = [int(v) for v in boxes[k]]
         m = (initial_masks[0] == mid).float()[y0:y1 + 1, x0:x1 + 1]
         rgb_crops[k] = F.interpolate(rgb[0:1, :, y0:y1 + 1, x0:x1 + 1], size=(S, S), mode="bilinear", align_corners=True)[0]
-        depth_crops[k] = F.interpolate(depth[0:1, :, y0:y1 + 1, x0:x1 + 1], size=(S, S), mode="bilinear", align_corners=True)[0]
+        if depth is not None:
+            depth_crops[k] = F.interpolate(depth[0:1, :, y0:y1 + 1, x0:x1 + 1], size=(S, S), mode="bilinear", align_corners=True)[0]
         mask_crops[k] = F.interpolate(m[None, None], size=(S, S), mode="nearest")[0, 0]
     return rgb_crops, mask_crops, boxes.float(), depth_crops
 
@@ -83,6 +84,9 @@ def match_label_crop(initial_masks: torch.Tensor, labels_crop: torch.Tensor, out
                 labels_crop[i][sel] = -1
     keys = []
     for i in range(K):                                         # :129-138 mean depth of kept pixels
+        if depth_crop is None:                                 # :139-146 no depth: box area, large first
+            keys.append((i, (rois[i, 3] - rois[i, 1] + 1) * (rois[i, 2] - rois[i, 0] + 1)))
+            continue
         kept = labels_crop[i] > -1
         z = depth_crop[i, 2][kept] if torch.sum(kept) > 0 else depth_crop[i, 2]
         keys.append((i, torch.mean(z[z > 0])))
@@ -123,7 +127,8 @@ def test_sample(image: torch.Tensor, depth: torch.Tensor, network, network_crop,
     features = network(image, None, depth)
     n = features.shape[2] * features.shape[3]
     out_label = clustering_features(features, [rng.randint(0, n) for _ in range(features.shape[0])])
-    out_label = filter_labels_depth(out_label, depth, 0.8)
+    if depth is not None:                                      # :250
+        out_label = filter_labels_depth(out_label, depth, 0.8)
     refined = None
     if network_crop is not None:
         rgb_c, mask_c, rois, depth_c = crop_rois(image, out_label.clone(), depth)

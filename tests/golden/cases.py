@@ -88,3 +88,18 @@ def e2e_stub_features(seed, H, W, objects):
     return torch.from_numpy(X).view(H, W, 64).permute(2, 0, 1)[None].contiguous()
 
 
+# ---------------------------------------------------------------------------------------------
+# Other input modalities: cfg.INPUT 'COLOR' / 'DEPTH', RGBD with FUSION_TYPE 'early'.
+# ---------------------------------------------------------------------------------------------
+MODES = {
+    # mode -> (cfg.INPUT, cfg.TRAIN.FUSION_TYPE, factory name, stem input channels)
+    "COLOR":      dict(INPUT="COLOR", FUSION="add",   factory="seg_resnet34_8s_embedding",       in_channels=3),
+    "DEPTH":      dict(INPUT="DEPTH", FUSION="add",   factory="seg_resnet34_8s_embedding",       in_channels=3),
+    "RGBD_EARLY": dict(INPUT="RGBD",  FUSION="early", factory="seg_resnet34_8s_embedding_early", in_channels=6),
+}
+MODE_BACKBONE_CASES = {
+    "tiny_64x64":  dict(wseed=5, frames=[7], H=64, W=64, samples=0),
+    "odd_72x104":  dict(wseed=6, frames=[8, 9], H=72, W=104, samples=1024),
+}
+MODE_GLUE_CASES = ["normal_5", "border_8", "small_ragged"]       # GLUE_CASES re-run without depth (COLOR input)
+MODE_E2E_CASES = {"color_a": dict(seed=43, objects=4)}

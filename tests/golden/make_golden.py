@@ -4,7 +4,7 @@ Imports the reference's own Python (through tests/golden/ref_harness.py) and rec
 outputs on repo-owned synthetic inputs.  The .npz files written next to this script are the
 fixtures tests/ compares the oracle (CPU) and the HIP path (GPU) against.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [meanshift|glue|backbone|e2e|all]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [meanshift|glue|backbone|e2e|demo|modes|all]
 """
 from __future__ import annotations
 
@@ -21,6 +21,7 @@ sys.path.insert(0, HERE)
 
 import ref_harness  # noqa: E402
 from cases import (MEANSHIFT_CASES, KAPPA, EPSILON, RNG_SEED, BACKBONE_CASES, GLUE_CASES, E2E_CASES,  # noqa: E402
+                   MODES, MODE_BACKBONE_CASES, MODE_GLUE_CASES, MODE_E2E_CASES,
                    sample_positions, glue_inputs, crop_cluster_labels, e2e_stub_features)
 from unseenobjectclustering_amd import synth  # noqa: E402
 
@@ -149,6 +150,74 @@ def make_demo(ref):
     print("demo: labels", np.unique(out_label.numpy()).tolist(), "refined", np.unique(refined.numpy()).tolist(), flush=True)
 
 
+def make_modes(ref):
+    """Other modalities: the reference's SEGNET built under cfg.INPUT / FUSION_TYPE of each mode, and its
+    glue / test_sample with depth=None (COLOR input: no depth filter, ROI order by box area)."""
+    import contextlib
+    import io
+    td = ref.test_dataset
+    out = {}
+    saved = (ref.cfg.INPUT, ref.cfg.TRAIN.FUSION_TYPE)
+    try:
+        for mode, m in MODES.items():
+            ref.cfg.INPUT, ref.cfg.TRAIN.FUSION_TYPE = m["INPUT"], m["FUSION"]
+            for name, c in MODE_BACKBONE_CASES.items():
+                sd = {k: torch.from_numpy(np.asarray(v))
+                      for k, v in synth.synthetic_state_dict(c["wseed"], branches=("fcn",), in_channels=m["in_channels"]).items()}
+                with contextlib.redirect_stdout(io.StringIO()):
+                    net = ref.networks.__dict__[m["factory"]](2, 64, sd).eval()
+                assert not hasattr(net, "fcn_depth")
+                got = net.state_dict()
+                assert all(torch.equal(got[k], v) for k, v in sd.items()), "update_model dropped an entry"
+                frames = [synth.rgbd_frame(s_, c["H"], c["W"], 4) for s_ in c["frames"]]
+                img = torch.from_numpy(np.concatenate([f["image_color"] for f in frames]))
+                dep = torch.from_numpy(np.concatenate([f["depth"] for f in frames]))
+                with torch.no_grad():
+                    feat = net(img, None, None if mode == "COLOR" else dep)
+                B = feat.shape[0]
+                flat = feat.permute(0, 2, 3, 1).reshape(B, -1, 64).numpy()
+                key = f"{mode}/{name}"
+                if c["samples"]:
+                    pos = sample_positions(99, flat.shape[1], c["samples"])
+                    out[key + "/pos"] = pos
+                    out[key + "/embed"] = flat[:, pos].astype(np.float32)
+                else:
+                    out[key + "/embed"] = flat.astype(np.float32)
+                print(key, feat.shape, "norm check", float(feat.norm(dim=1).mean()), flush=True)
+
+        ref.cfg.INPUT, ref.cfg.TRAIN.FUSION_TYPE = "COLOR", "add"
+        for name in MODE_GLUE_CASES:
+            c = GLUE_CASES[name]
+            img, lab, depth, gt = glue_inputs(c)
+            rgb_c, mask_c, rois, depth_c = td.crop_rois(img, lab.clone(), None)        # no depth filter either (:250)
+            assert depth_c is None
+            K = rgb_c.shape[0]
+            key = "COLOR/glue_" + name
+            out[key + "/rois"] = rois.numpy().astype(np.int32)
+            out[key + "/mask_crops"] = np.packbits(mask_c.numpy().astype(np.uint8), axis=None)
+            out[key + "/rgb_crops_sum"] = rgb_c.double().sum(dim=(1, 2, 3)).numpy()
+            labels_c = crop_cluster_labels(c, gt, rois)
+            refined, labels_c2 = td.match_label_crop(lab, labels_c.clone(), mask_c, rois, None)
+            out[key + "/refined"] = refined.numpy().astype(np.uint8)
+            out[key + "/labels_crop_out"] = labels_c2.numpy().astype(np.int8)
+            print(key, "K =", K, flush=True)
+
+        for name, c in MODE_E2E_CASES.items():
+            fr = synth.rgbd_frame(c["seed"], 480, 640, c["objects"])
+            sample = dict(image_color=torch.from_numpy(fr["image_color"]))           # COLOR samples carry no depth
+            net = lambda img, label, depth, c=c: e2e_stub_features(c["seed"], 480, 640, c["objects"] + 2)
+            net_crop = lambda rgb, label, depth, c=c: torch.cat(
+                [e2e_stub_features(1000 + 10 * c["seed"] + k, 224, 224, 2 + k % 3) for k in range(rgb.shape[0])])
+            np.random.seed(RNG_SEED)
+            out_label, refined = td.test_sample(sample, net, net_crop)
+            out[f"COLOR/{name}/out_label"] = out_label.numpy().astype(np.uint8)
+            out[f"COLOR/{name}/refined"] = refined.numpy().astype(np.uint8)
+            print("COLOR", name, "labels", np.unique(out_label.numpy()).tolist(), "refined", np.unique(refined.numpy()).tolist(), flush=True)
+    finally:
+        ref.cfg.INPUT, ref.cfg.TRAIN.FUSION_TYPE = saved
+    np.savez_compressed(os.path.join(HERE, "modes.npz"), **out)
+
+
 def main():
     assert ref_harness.available(), "reference tree not present: golden vectors can only be made in the build container"
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -164,6 +233,8 @@ def main():
         make_e2e(ref)
     if what in ("demo", "all"):
         make_demo(ref)
+    if what in ("modes", "all"):
+        make_modes(ref)
 
 
 if __name__ == "__main__":

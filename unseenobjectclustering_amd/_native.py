@@ -29,6 +29,7 @@ def _declare(lib):
     lib.uoc_ms_assign.argtypes = [P, c_int, c_int, P, P, P, c_int, P, P, P, c_size_t, P]
     lib.uoc_ms_cluster.argtypes = [P, c_int, c_int, c_int, c_float, c_int, c_float, P, P, P, P, P, P, c_size_t, P]
     lib.uoc_net_create.argtypes = [POINTER(P)]
+    lib.uoc_net_create_mode.argtypes = [POINTER(P), c_int]
     lib.uoc_net_destroy.argtypes = [P]
     lib.uoc_net_load_param.argtypes = [P, c_char_p, P, c_size_t]
     lib.uoc_net_finalize.argtypes = [P]
@@ -36,7 +37,7 @@ def _declare(lib):
     lib.uoc_net_workspace_bytes.argtypes = [P, c_int, c_int, c_int]
     lib.uoc_net_forward.argtypes = [P, P, P, c_int, c_int, c_int, P, P, c_size_t, P]
     lib.uoc_conv2d_nhwc.argtypes = [P, P, P, P, P] + [c_int] * 11 + [P]
-    for name in ("uoc_net_create", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_forward",
+    for name in ("uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_forward",
                  "uoc_conv2d_nhwc"):
         getattr(lib, name).restype = c_int
     lib.uoc_roi_workspace_bytes.restype = c_size_t
@@ -64,7 +65,7 @@ def _declare(lib):
 EXPORTED_SYMBOLS = (
     "uoc_version", "uoc_last_error", "uoc_ms_set_persistent_fps", "uoc_ms_workspace_bytes", "uoc_ms_select_seeds", "uoc_ms_hill_climb",
     "uoc_ms_seed_components", "uoc_ms_assign", "uoc_ms_cluster",
-    "uoc_net_create", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",
+    "uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",
     "uoc_net_forward", "uoc_conv2d_nhwc",
     "uoc_roi_workspace_bytes", "uoc_prep_rgbd", "uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats",
     "uoc_roi_paste", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",

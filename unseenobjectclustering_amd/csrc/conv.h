@@ -31,7 +31,7 @@ int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_
 int launch_nchw3_to_nhwc4(const float *in, float *out, int B, int H, int W, hipStream_t st);
 // 3x3 s2 p1 max pooling, NHWC, C % 4 == 0; `n_img` images
 int launch_maxpool3x3s2(const float *in, float *out, int n_img, int H, int W, int C, int Ho, int Wo, hipStream_t st);
-// embed[b][p][:] = normalize(bilinear_up(a[b] + c[b]))  (align_corners=True), a,c: [B][h][w][64]
+// embed[b][p][:] = normalize(bilinear_up(a[b] + c[b]))  (align_corners=True), a,c: [B][h][w][64]; c may be null
 int launch_head(const float *fa, const float *fb, float *embed, int B, int h, int w, int H, int W, hipStream_t st);
 
 }  // namespace uoc

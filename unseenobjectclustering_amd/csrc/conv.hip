@@ -868,6 +868,7 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ fa,
     auto ld = [&](int y, int x) {
       const size_t o = base + ((size_t)y * w + x) * 64;
       const float4 u = *reinterpret_cast<const float4 *>(fa + o);
+      if (!fb) return u;  // single-backbone modes (COLOR / DEPTH / early fusion)
       const float4 v = *reinterpret_cast<const float4 *>(fb + o);
       return make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
     };
@@ -898,7 +899,7 @@ int launch_head(const float *fa, const float *fb, float *embed, int B, int h, in
   long blocks = (total / 4 + 3) / 4;  // 4 waves per block, 4 pixels per wave step
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  ProfScope prof(KC_HEAD, st, 0.0, 4.0 * 64 * ((double)total + 2.0 * B * h * w));
+  ProfScope prof(KC_HEAD, st, 0.0, 4.0 * 64 * ((double)total + (fb ? 2.0 : 1.0) * B * h * w));
   hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fa, fb, embed, B, h, w, H, W, sy, sx);
   UOC_LAUNCH_CHECK();
   return UOC_OK;

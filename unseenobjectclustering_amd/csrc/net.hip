@@ -41,12 +41,13 @@ struct uoc_net {
   bool finalized = false;
   int device = -1;
   int wino_min_cin = 256;  // 3x3 stride-1 layers with Cin >= this run as Winograd F(2x2,3x3); 0 = never
+  int mode = UOC_NET_RGBD_ADD;
+  int G = 2;  // backbones evaluated side by side (2 only for RGBD 'add')
 };
 
 namespace uoc {
 
 static const char *kBranch[2] = {"fcn", "fcn_depth"};
-constexpr int G = 2;
 
 static int add_conv(uoc_net *n, const std::string &conv, const std::string &bn, int Cin, int Cout, int K, int stride,
                     int dil, int relu, bool has_bn, bool has_bias, bool stem = false) {
@@ -68,7 +69,8 @@ static int add_conv(uoc_net *n, const std::string &conv, const std::string &bn, 
 }
 
 static void build_graph(uoc_net *n) {
-  n->stem = add_conv(n, "conv1", "bn1", 3, 64, 7, 2, 1, 1, true, false, true);
+  // early fusion feeds cat(img, xyz) to ONE backbone with a 6-channel stem (SEG.py:103-105,178-181)
+  n->stem = add_conv(n, "conv1", "bn1", n->mode == UOC_NET_RGBD_EARLY ? 6 : 3, 64, 7, 2, 1, 1, true, false, true);
   const int nblocks[4] = {3, 4, 6, 3};
   const int planes[4] = {64, 128, 256, 512};
   int inpl = 64, cur_stride = 4, cur_dil = 1;
@@ -114,10 +116,15 @@ static const std::vector<float> *find(const uoc_net *n, const std::string &key, 
 }
 
 static int finalize_layer(uoc_net *n, ConvLayer &L) {
+  const int G = n->G;
   const int T = L.stem ? 7 : L.K * L.K;
   const int Kc = L.stem ? 32 : L.Cin;
+  // The stem kernel consumes 4-channel pixels (3 used).  A 6-channel stem is stored as two 3-channel
+  // weight sets [set][kh][cout][kw(8)][ch(4)] and evaluated as conv(xyz, set 1) then conv(img, set 0) + that.
+  const int sets = L.stem ? L.Cin / 3 : 1;
   L.w_per_group = (size_t)T * L.Cout * Kc;
-  std::vector<float> hw((size_t)G * L.w_per_group, 0.f), hb((size_t)G * L.Cout, 0.f);
+  // one extra all-zero bias row (used by the partial stem pass)
+  std::vector<float> hw((size_t)G * sets * L.w_per_group, 0.f), hb((size_t)(G + 1) * L.Cout, 0.f);
   for (int g = 0; g < G; ++g) {
     const std::string base = std::string(kBranch[g]) + ".resnet34_8s.";
     const auto *w = find(n, base + L.conv + ".weight", (size_t)L.Cout * L.Cin * L.K * L.K);
@@ -140,15 +147,15 @@ static int finalize_layer(uoc_net *n, ConvLayer &L) {
       if (!bi) return UOC_ENOENT;
       for (int c = 0; c < L.Cout; ++c) shift[c] += (double)(*bi)[c];
     }
-    float *dst = hw.data() + (size_t)g * L.w_per_group;
+    float *dst = hw.data() + (size_t)g * sets * L.w_per_group;
     for (int co = 0; co < L.Cout; ++co)
       for (int ci = 0; ci < L.Cin; ++ci)
         for (int kh = 0; kh < L.K; ++kh)
           for (int kw = 0; kw < L.K; ++kw) {
             const double v = (double)(*w)[(((size_t)co * L.Cin + ci) * L.K + kh) * L.K + kw] * scale[co];
             size_t o;
-            if (L.stem)  // [kh][cout][kw(8)][ch(4)]
-              o = ((size_t)kh * L.Cout + co) * 32 + kw * 4 + ci;
+            if (L.stem)  // [set][kh][cout][kw(8)][ch(4)]
+              o = (size_t)(ci / 3) * L.w_per_group + ((size_t)kh * L.Cout + co) * 32 + kw * 4 + ci % 3;
             else  // [tap][cout][cin]
               o = ((size_t)(kh * L.K + kw) * L.Cout + co) * L.Cin + ci;
             dst[o] = (float)v;
@@ -186,11 +193,13 @@ static Dims dims(int H, int W) {
 }
 
 struct NetWs {
-  float *in4, *stem, *buf[4], *fc, *wino;
+  float *in4, *stem, *stem_part, *buf[4], *fc, *wino;
   size_t total;
 };
-static NetWs carve_net(void *base, int B, int H, int W) {
+static NetWs carve_net(void *base, int mode, int B, int H, int W) {
   const Dims d = dims(H, W);
+  const int G = mode == UOC_NET_RGBD_ADD ? 2 : 1;
+  const int n_in = (mode == UOC_NET_RGBD_ADD || mode == UOC_NET_RGBD_EARLY) ? 2 : 1;
   NetWs w;
   size_t off = 0;
   auto take = [&](size_t floats) {
@@ -198,8 +207,9 @@ static NetWs carve_net(void *base, int B, int H, int W) {
     off += align_up(floats * sizeof(float), 256);
     return p;
   };
-  w.in4 = take((size_t)G * B * H * W * 4);
+  w.in4 = take((size_t)n_in * B * H * W * 4);
   w.stem = take((size_t)G * B * d.H1 * d.W1 * 64);
+  w.stem_part = mode == UOC_NET_RGBD_EARLY ? take((size_t)B * d.H1 * d.W1 * 64) : nullptr;
   size_t act = (size_t)G * B * d.H2 * d.W2 * 64;
   const size_t a3 = (size_t)G * B * d.H3 * d.W3 * 512;
   if (a3 > act) act = a3;
@@ -218,8 +228,8 @@ static NetWs carve_net(void *base, int B, int H, int W) {
   return w;
 }
 
-static int run_conv(const ConvLayer &L, const float *in, const float *res, float *out, int B, int H, int W, int Ho,
-                    int Wo, hipStream_t st, float *wino_ws = nullptr) {
+static int run_conv(int G, const ConvLayer &L, const float *in, const float *res, float *out, int B, int H, int W,
+                    int Ho, int Wo, hipStream_t st, float *wino_ws = nullptr) {
   ConvParams p;
   p.in = in;
   p.w = L.d_w;
@@ -250,13 +260,18 @@ using namespace uoc;
 
 extern "C" {
 
-int uoc_net_create(uoc_net **out) {
+int uoc_net_create(uoc_net **out) { return uoc_net_create_mode(out, UOC_NET_RGBD_ADD); }
+
+int uoc_net_create_mode(uoc_net **out, int mode) {
   UOC_REQUIRE(out != nullptr, "out is null");
+  UOC_REQUIRE(mode >= UOC_NET_RGBD_ADD && mode <= UOC_NET_RGBD_EARLY, "unknown network mode %d", mode);
   uoc_net *n = new (std::nothrow) uoc_net();
   if (!n) {
     set_error("out of host memory");
     return UOC_ENOMEM;
   }
+  n->mode = mode;
+  n->G = mode == UOC_NET_RGBD_ADD ? 2 : 1;
   build_graph(n);
   if (const char *e = getenv("UOC_WINOGRAD_MIN_CIN")) n->wino_min_cin = atoi(e);  // 0 disables the Winograd path
   *out = n;
@@ -293,26 +308,44 @@ int uoc_net_finalize(uoc_net *n) {
 }
 
 size_t uoc_net_workspace_bytes(const uoc_net *n, int B, int H, int W) {
-  (void)n;
-  if (B < 1 || H < 8 || W < 8) return 0;
-  return carve_net(nullptr, B, H, W).total;
+  if (!n || B < 1 || H < 8 || W < 8) return 0;
+  return carve_net(nullptr, n->mode, B, H, W).total;
 }
 
 int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, int H, int W, float *d_embed,
                     void *d_ws, size_t ws_bytes, void *stream) {
   UOC_REQUIRE(n && n->finalized, "network not finalized");
-  UOC_REQUIRE(d_rgb && d_xyz && d_embed, "null tensor pointer");
+  UOC_REQUIRE(d_embed && (d_rgb || n->mode == UOC_NET_DEPTH) && (d_xyz || n->mode == UOC_NET_COLOR),
+              "null tensor pointer");
   UOC_REQUIRE(B >= 1 && H >= 8 && W >= 8, "bad input shape B=%d H=%d W=%d", B, H, W);
-  const NetWs w = carve_net(d_ws, B, H, W);
+  const int G = n->G;
+  const NetWs w = carve_net(d_ws, n->mode, B, H, W);
   UOC_REQUIRE(d_ws && ws_bytes >= w.total && ((uintptr_t)d_ws & 255) == 0, "workspace too small or misaligned (%zu < %zu)",
               ws_bytes, w.total);
   hipStream_t st = (hipStream_t)stream;
   const Dims d = dims(H, W);
 
-  // inputs -> NHWC4, group 0 = BGR image, group 1 = XYZ
-  if (int rc = launch_nchw3_to_nhwc4(d_rgb, w.in4, B, H, W, st)) return rc;
-  if (int rc = launch_nchw3_to_nhwc4(d_xyz, w.in4 + (size_t)B * H * W * 4, B, H, W, st)) return rc;
-  if (int rc = run_conv(n->layers[n->stem], w.in4, nullptr, w.stem, B, H, W, d.H1, d.W1, st)) return rc;
+  const ConvLayer &stem = n->layers[n->stem];
+  const size_t in_stride = (size_t)B * H * W * 4;
+  if (n->mode == UOC_NET_RGBD_EARLY) {
+    // 6-channel stem as two 3-channel passes: XYZ part first (no bias, no ReLU), then the image part
+    // with the folded-BN bias, the first pass as its residual, and the ReLU.
+    if (int rc = launch_nchw3_to_nhwc4(d_rgb, w.in4, B, H, W, st)) return rc;
+    if (int rc = launch_nchw3_to_nhwc4(d_xyz, w.in4 + in_stride, B, H, W, st)) return rc;
+    ConvLayer part = stem;
+    part.d_w = stem.d_w + stem.w_per_group;
+    part.d_b = stem.d_b + (size_t)G * stem.Cout;  // the all-zero row
+    part.relu = 0;
+    if (int rc = run_conv(1, part, w.in4 + in_stride, nullptr, w.stem_part, B, H, W, d.H1, d.W1, st)) return rc;
+    if (int rc = run_conv(1, stem, w.in4, w.stem_part, w.stem, B, H, W, d.H1, d.W1, st)) return rc;
+  } else {
+    // inputs -> NHWC4; RGBD 'add': group 0 = BGR image, group 1 = XYZ
+    const float *first = n->mode == UOC_NET_DEPTH ? d_xyz : d_rgb;
+    if (int rc = launch_nchw3_to_nhwc4(first, w.in4, B, H, W, st)) return rc;
+    if (G == 2)
+      if (int rc = launch_nchw3_to_nhwc4(d_xyz, w.in4 + in_stride, B, H, W, st)) return rc;
+    if (int rc = run_conv(G, stem, w.in4, nullptr, w.stem, B, H, W, d.H1, d.W1, st)) return rc;
+  }
   if (int rc = launch_maxpool3x3s2(w.stem, w.buf[0], G * B, d.H1, d.W1, 64, d.H2, d.W2, st)) return rc;
 
   int cur = 0, h = d.H2, wd = d.W2;
@@ -320,19 +353,19 @@ int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, i
     const ConvLayer &c1 = n->layers[b.conv1], &c2 = n->layers[b.conv2];
     const int ho = (h - 1) / c1.stride + 1, wo = (wd - 1) / c1.stride + 1;
     float *x = w.buf[cur], *tmp = w.buf[(cur + 1) & 3], *sc = w.buf[(cur + 2) & 3], *y = w.buf[(cur + 3) & 3];
-    if (int rc = run_conv(c1, x, nullptr, tmp, B, h, wd, ho, wo, st, w.wino)) return rc;
+    if (int rc = run_conv(G, c1, x, nullptr, tmp, B, h, wd, ho, wo, st, w.wino)) return rc;
     const float *res = x;
     if (b.down >= 0) {
-      if (int rc = run_conv(n->layers[b.down], x, nullptr, sc, B, h, wd, ho, wo, st)) return rc;
+      if (int rc = run_conv(G, n->layers[b.down], x, nullptr, sc, B, h, wd, ho, wo, st)) return rc;
       res = sc;
     }
-    if (int rc = run_conv(c2, tmp, res, y, B, ho, wo, ho, wo, st, w.wino)) return rc;
+    if (int rc = run_conv(G, c2, tmp, res, y, B, ho, wo, ho, wo, st, w.wino)) return rc;
     cur = (cur + 3) & 3;
     h = ho;
     wd = wo;
   }
-  if (int rc = run_conv(n->layers[n->fc], w.buf[cur], nullptr, w.fc, B, h, wd, h, wd, st)) return rc;
-  return launch_head(w.fc, w.fc + (size_t)B * h * wd * 64, d_embed, B, h, wd, H, W, st);
+  if (int rc = run_conv(G, n->layers[n->fc], w.buf[cur], nullptr, w.fc, B, h, wd, h, wd, st)) return rc;
+  return launch_head(w.fc, G == 2 ? w.fc + (size_t)B * h * wd * 64 : nullptr, d_embed, B, h, wd, H, W, st);
 }
 
 /* Generic NHWC convolution entry (unit tests / integration): G independent groups stacked on the

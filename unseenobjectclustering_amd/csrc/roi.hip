@@ -126,8 +126,10 @@ __global__ __launch_bounds__(256) void roi_crop_kernel(const float *__restrict__
   for (int c = 0; c < 3; ++c) {
     const float *a = rgb + c * HW;
     out_rgb[((size_t)k * 3 + c) * SS + i] = (a[o00] * hx + a[o01] * lx) * hy + (a[o10] * hx + a[o11] * lx) * ly;
-    const float *d = xyz + c * HW;
-    out_xyz[((size_t)k * 3 + c) * SS + i] = (d[o00] * hx + d[o01] * lx) * hy + (d[o10] * hx + d[o11] * lx) * ly;
+    if (xyz) {  // COLOR input has no XYZ planes (crop_rois :73-76)
+      const float *d = xyz + c * HW;
+      out_xyz[((size_t)k * 3 + c) * SS + i] = (d[o00] * hx + d[o01] * lx) * hy + (d[o10] * hx + d[o11] * lx) * ly;
+    }
   }
   // nearest (:106)
   int my = (int)floorf((float)oy * ny), mx = (int)floorf((float)ox * nx);
@@ -181,6 +183,7 @@ __global__ __launch_bounds__(1024) void crop_meanz_kernel(const int *__restrict_
     if (kp) atomicOr(&s_any, 1);
   }
   __syncthreads();
+  if (!xyz_crop) return;  // no depth: the host orders ROIs by box area instead (:138-146)
   const int any = s_any;
   const float *z = xyz_crop + ((size_t)k * 3 + 2) * SS;
   const int *lab = labels_crop + (size_t)k * SS;
@@ -354,7 +357,8 @@ int uoc_roi_build(int32_t *d_labels, const float *d_z, int H, int W, float thres
 int uoc_roi_crop(const float *d_rgb, const float *d_xyz, const int32_t *d_labels, int H, int W,
                  const uoc_roi_table *d_table, int K, int S, float *d_rgb_crops, float *d_xyz_crops,
                  float *d_mask_crops, void *stream) {
-  UOC_REQUIRE(d_rgb && d_xyz && d_labels && d_table && d_rgb_crops && d_xyz_crops && d_mask_crops, "null pointer");
+  UOC_REQUIRE(d_rgb && d_labels && d_table && d_rgb_crops && d_mask_crops, "null pointer");
+  UOC_REQUIRE((d_xyz == nullptr) == (d_xyz_crops == nullptr), "d_xyz and d_xyz_crops must be given together");
   UOC_REQUIRE(K >= 1 && K < NL && S >= 1, "K=%d S=%d out of range", K, S);
   hipLaunchKernelGGL(roi_crop_kernel, dim3((S * S + 255) / 256, K), dim3(256), 0, (hipStream_t)stream, d_rgb, d_xyz,
                      d_labels, H, W, d_table, S, d_rgb_crops, d_xyz_crops, d_mask_crops);
@@ -364,7 +368,8 @@ int uoc_roi_crop(const float *d_rgb, const float *d_xyz, const int32_t *d_labels
 
 int uoc_roi_match_stats(const int32_t *d_labels_crop, const float *d_mask_crops, const float *d_xyz_crops, int K,
                         int S, int32_t *d_keep, float *d_meanz, void *d_ws, size_t ws_bytes, void *stream) {
-  UOC_REQUIRE(d_labels_crop && d_mask_crops && d_xyz_crops && d_keep && d_meanz && d_ws, "null pointer");
+  UOC_REQUIRE(d_labels_crop && d_mask_crops && d_keep && d_ws, "null pointer");
+  UOC_REQUIRE(d_xyz_crops == nullptr || d_meanz != nullptr, "d_meanz is null");
   UOC_REQUIRE(K >= 1 && K < NL && S >= 1, "K=%d S=%d out of range", K, S);
   RoiWs w = carve_roi(d_ws);
   UOC_REQUIRE(ws_bytes >= w.total, "workspace too small");

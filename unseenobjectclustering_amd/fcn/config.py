@@ -1,6 +1,8 @@
 """Process-global config object `cfg` — the subset of the reference's lib/fcn/config.py that the
 inference hot path reads, with the values the RGB-D `add` / cosine experiment
-config sets (experiments/cfgs/seg_resnet34_8s_embedding_cosine_rgbd_add_tabletop.yml).
+config sets (experiments/cfgs/seg_resnet34_8s_embedding_cosine_rgbd_add_tabletop.yml).  cfg.INPUT
+'COLOR' / 'DEPTH' and FUSION_TYPE 'early' (the other shipped experiment configs) are implemented too;
+'cat' is not.
 
 The reference's default EMBEDDING_METRIC is 'euclidean' (config.py:261) and every shipped
 experiment overrides it to 'cosine'; this build implements the cosine path only and raises if
@@ -43,11 +45,31 @@ cfg.TEST = AttrDict()
 cfg.TEST.VISUALIZE = False             # config.py:319
 
 
+def network_mode() -> str:
+    """'RGBD_ADD' | 'COLOR' | 'DEPTH' | 'RGBD_EARLY' from cfg.INPUT / cfg.TRAIN.FUSION_TYPE (SEG.py:69-71,97-110)."""
+    if cfg.INPUT == "COLOR":
+        return "COLOR"
+    if cfg.INPUT == "DEPTH":
+        return "DEPTH"
+    if cfg.INPUT == "RGBD":
+        if cfg.TRAIN.FUSION_TYPE == "add":
+            return "RGBD_ADD"
+        if cfg.TRAIN.FUSION_TYPE == "early":
+            return "RGBD_EARLY"
+        raise NotImplementedError("cfg.TRAIN.FUSION_TYPE=%r: only 'add' and 'early' are implemented on gfx950 "
+                                  "('cat' needs 128-d clustering kernels)" % (cfg.TRAIN.FUSION_TYPE,))
+    raise NotImplementedError("cfg.INPUT=%r is not one of 'RGBD', 'COLOR', 'DEPTH'" % (cfg.INPUT,))
+
+
+def uses_depth() -> bool:
+    """test_dataset.py:236 / tools/test_images.py:110: depth is read for DEPTH and RGBD inputs."""
+    return cfg.INPUT in ("DEPTH", "RGBD")
+
+
 def require_supported():
-    """The HIP path implements exactly one configuration; fail loudly on anything else."""
+    """Fail loudly on configurations the HIP path does not implement (there is no fallback)."""
     if cfg.TRAIN.EMBEDDING_METRIC != "cosine":
         raise NotImplementedError("only cfg.TRAIN.EMBEDDING_METRIC='cosine' is implemented on gfx950")
-    if cfg.INPUT != "RGBD" or cfg.TRAIN.FUSION_TYPE != "add":
-        raise NotImplementedError("only cfg.INPUT='RGBD' with cfg.TRAIN.FUSION_TYPE='add' is implemented")
+    network_mode()
     if not cfg.TRAIN.EMBEDDING_NORMALIZATION:
         raise NotImplementedError("EMBEDDING_NORMALIZATION=False is not implemented")

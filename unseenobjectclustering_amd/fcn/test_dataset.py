@@ -19,7 +19,7 @@ import torch
 
 from .. import _native
 from ..utils.mean_shift import cluster_batch
-from .config import cfg, require_supported
+from .config import cfg, require_supported, uses_depth
 
 KAPPA = 20            # test_dataset.py:51
 MAX_ITERS = 10        # :56
@@ -119,7 +119,7 @@ def _crop(rgb, depth, lab0, table, K, H, W, dev):
     S = cfg.TRAIN.SYN_CROP_SIZE
     L = _native.lib()
     rgb_crops = torch.empty((K, 3, S, S), dtype=torch.float32, device=dev)
-    depth_crops = torch.empty((K, 3, S, S), dtype=torch.float32, device=dev)
+    depth_crops = torch.empty((K, 3, S, S), dtype=torch.float32, device=dev) if depth is not None else None   # :73-76
     mask_crops = torch.empty((K, S, S), dtype=torch.float32, device=dev)
     if K > 0:
         with torch.cuda.device(dev):
@@ -132,11 +132,9 @@ def _crop(rgb, depth, lab0, table, K, H, W, dev):
 
 def crop_rois(rgb, initial_masks, depth):
     """test_dataset.py:62-112 -> (rgb_crops [K,3,S,S], mask_crops [K,S,S], rois [K,4], depth_crops)."""
-    if depth is None:
-        raise NotImplementedError("RGB-D path only: depth must be given")
     dev = rgb.device if rgb.is_cuda else _device()
     rgb = rgb.to(dev).float().contiguous()
-    depth = depth.to(dev).float().contiguous()
+    depth = depth.to(dev).float().contiguous() if depth is not None else None
     N, H, W = initial_masks.shape
     lab0 = _labels_to_device(initial_masks[0], dev)
     table = _build_rois(lab0, ctypes.c_void_p(0), H, W, dev)
@@ -147,12 +145,12 @@ def crop_rois(rgb, initial_masks, depth):
     return rgb_crops, mask_crops, rois, depth_crops
 
 
-def _order_and_map(keep: np.ndarray, meanz: torch.Tensor):
-    """Host part of match_label_crop: ROI paint order by mean depth, far first (:150-151, Python's
-    stable sort with reverse=True on the 0-dim tensors, NaN behaviour included) and the global
-    renumbering of kept clusters in that order (:156-163)."""
+def _order_and_map(keep: np.ndarray, sort_key: torch.Tensor):
+    """Host part of match_label_crop: ROI paint order by mean depth, far first — or by box area, large
+    first, when there is no depth (:129-151, Python's stable sort with reverse=True on the 0-dim
+    tensors, NaN behaviour included) and the global renumbering of kept clusters in that order (:156-163)."""
     K = keep.shape[0]
-    keys = [(i, meanz[i]) for i in range(K)]
+    keys = [(i, sort_key[i]) for i in range(K)]
     order = [i for i, _ in sorted(keys, key=lambda kv: kv[1], reverse=True)]
     mapping = np.zeros((K, MAX_LABELS), dtype=np.int32)
     count = 0
@@ -169,14 +167,19 @@ def _match(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev):
     L = _native.lib()
     ws = _ws(dev)
     keep = torch.empty((K, MAX_LABELS), dtype=torch.int32, device=dev)
-    meanz = torch.empty((K,), dtype=torch.float32, device=dev)
+    meanz = torch.empty((K,), dtype=torch.float32, device=dev) if depth_crops is not None else None
     with torch.cuda.device(dev):
         rc = L.uoc_roi_match_stats(_native.ptr(labels_crop_i32), _native.ptr(mask_crops), _native.ptr(depth_crops), K, S,
                                    _native.ptr(keep), _native.ptr(meanz), _native.ptr(ws), ws.numel(),
                                    _native.stream_ptr(dev))
     _native.check(rc, "uoc_roi_match_stats")
     keep_h = keep.cpu().numpy()
-    order, mapping = _order_and_map(keep_h, meanz.cpu())
+    if meanz is not None:
+        sort_key = meanz.cpu()
+    else:       # :138-146 roi_size = (y_max - y_min + 1) * (x_max - x_min + 1), float32 like the reference's rois
+        box = torch.tensor(np.ctypeslib.as_array(_read_table(table).box)[:K].astype(np.float32))
+        sort_key = (box[:, 3] - box[:, 1] + 1) * (box[:, 2] - box[:, 0] + 1)
+    order, mapping = _order_and_map(keep_h, sort_key)
     order_d = torch.from_numpy(order).to(dev)
     map_d = torch.from_numpy(mapping).to(dev)
     refined = torch.empty((H * W,), dtype=torch.int32, device=dev)
@@ -189,8 +192,6 @@ def _match(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev):
 
 def match_label_crop(initial_masks, labels_crop, out_label_crop, rois, depth_crop):
     """test_dataset.py:116-179 -> (refined_masks like initial_masks (float), labels_crop with rejected = -1)."""
-    if depth_crop is None:
-        raise NotImplementedError("RGB-D path only: depth_crop must be given")
     dev = labels_crop.device if labels_crop.is_cuda else _device()
     K = labels_crop.shape[0]
     N, H, W = initial_masks.shape
@@ -205,7 +206,8 @@ def match_label_crop(initial_masks, labels_crop, out_label_crop, rois, depth_cro
         for i in range(4):
             t.box[k][i] = int(r[k, i])
     table = torch.frombuffer(bytearray(bytes(t)), dtype=torch.uint8).to(dev)
-    refined, keep = _match(lab, out_label_crop.to(dev).float().contiguous(), depth_crop.to(dev).float().contiguous(),
+    refined, keep = _match(lab, out_label_crop.to(dev).float().contiguous(),
+                           depth_crop.to(dev).float().contiguous() if depth_crop is not None else None,
                            table, K, H, W, dev)
     refined_masks[0] = refined.view(H, W).float().to(refined_masks.device)
     kept = torch.gather(keep, 1, lab.long()) != 0
@@ -228,7 +230,9 @@ def _run_frame(sample, network, network_crop, depth_threshold, return_device=Fal
         from ..io import prepare_on_device
         sample = dict(sample, **prepare_on_device(sample, dev))
     image = sample["image_color"].to(dev).float().contiguous()
-    depth = sample["depth"].to(dev).float().contiguous()
+    depth = sample["depth"].to(dev).float().contiguous() if uses_depth() else None       # :236-239
+    if depth is None:
+        depth_threshold = None                                                            # :250 `if depth is not None`
     label = sample["label"].to(dev) if "label" in sample else None
     B, _, H, W = image.shape
 

@@ -1,5 +1,6 @@
-"""SEGNET for cfg.INPUT='RGBD', FUSION_TYPE='add', network 'Resnet34_8s' — host-side mirror of
-/root/reference/lib/networks/SEG.py:26-176.
+"""SEGNET for network 'Resnet34_8s' — cfg.INPUT='RGBD' with FUSION_TYPE 'add' (two backbones) or
+'early' (one 6-channel backbone), 'COLOR', 'DEPTH' — host-side mirror of
+/root/reference/lib/networks/SEG.py:26-181.
 
 The module only OWNS the parameters (same state-dict keys as the reference:
 ``fcn.resnet34_8s.*`` / ``fcn_depth.resnet34_8s.*``, SEG.py:69-71) and hands them to the native
@@ -17,10 +18,11 @@ import torch
 import torch.nn as nn
 
 from .. import _native
-from ..fcn.config import cfg, require_supported
+from ..fcn.config import cfg, network_mode, require_supported
 from ..synth import resnet34_8s_param_shapes
 
 BRANCHES = ("fcn", "fcn_depth")
+_MODE_ID = {"RGBD_ADD": 0, "COLOR": 1, "DEPTH": 2, "RGBD_EARLY": 3}     # include/uoc_hip.h UOC_NET_*
 
 
 class _Node(nn.Module):
@@ -48,8 +50,12 @@ class SEGNET(nn.Module):
                  num_units=64, use_coordconv=False):
         super().__init__()
         require_supported()
-        if network_name != "Resnet34_8s" or in_channels != 3 or num_units != 64:
-            raise NotImplementedError("only Resnet34_8s, in_channels=3, num_units=64 is implemented on gfx950")
+        if network_name != "Resnet34_8s" or num_units != 64:
+            raise NotImplementedError("only Resnet34_8s with num_units=64 is implemented on gfx950")
+        self.mode = network_mode()
+        if in_channels != (6 if self.mode == "RGBD_EARLY" else 3):
+            raise ValueError("in_channels=%d does not fit cfg.INPUT=%r / FUSION_TYPE=%r (SEG.py:103-105: early fusion "
+                             "concatenates image and XYZ into 6 channels)" % (in_channels, cfg.INPUT, cfg.TRAIN.FUSION_TYPE))
         self.network_name = network_name
         self.in_channels = in_channels
         self.num_units = num_units
@@ -57,7 +63,9 @@ class SEGNET(nn.Module):
         self.normalize = cfg.TRAIN.EMBEDDING_NORMALIZATION
         self.input_type = cfg.INPUT
         self.fusion_type = cfg.TRAIN.FUSION_TYPE
-        for br in BRANCHES:
+        # SEG.py:69-71: fcn always; fcn_depth only for RGBD without early fusion
+        self.branches = BRANCHES if self.mode == "RGBD_ADD" else BRANCHES[:1]
+        for br in self.branches:
             for name, shape in resnet34_8s_param_shapes(num_units, in_channels):
                 if name.endswith("num_batches_tracked"):
                     t = torch.zeros((), dtype=torch.long)
@@ -102,7 +110,7 @@ class SEGNET(nn.Module):
         self._release()
         L = _native.lib()
         h = ctypes.c_void_p()
-        _native.check(L.uoc_net_create(ctypes.byref(h)), "uoc_net_create")
+        _native.check(L.uoc_net_create_mode(ctypes.byref(h), _MODE_ID[self.mode]), "uoc_net_create_mode")
         for key, t in self.state_dict().items():
             if key.endswith("num_batches_tracked"):
                 continue
@@ -118,15 +126,18 @@ class SEGNET(nn.Module):
     def forward(self, img, label=None, depth=None):
         if self.training:
             raise NotImplementedError("training (EmbeddingLoss) is out of scope; call .eval()")
-        if depth is None:
-            raise ValueError("RGBD network needs the XYZ `depth` tensor (SEG.py:105-106)")
-        if not img.is_cuda:
+        need_img, need_depth = self.mode != "DEPTH", self.mode != "COLOR"
+        if need_depth and depth is None:
+            raise ValueError("this network reads the XYZ `depth` tensor (SEG.py:97-106)")
+        lead = img if need_img else depth
+        if not lead.is_cuda:
             raise _native.NativeError("SEGNET.forward needs ROCm tensors (no CPU fallback); call .cuda() on the inputs")
-        dev = img.device
-        img = img.contiguous().float()
-        depth = depth.to(dev).contiguous().float()
-        B, C, H, W = img.shape
-        assert C == 3 and depth.shape == img.shape, "expects [B,3,H,W] image and XYZ tensors"
+        dev = lead.device
+        img = img.to(dev).contiguous().float() if need_img else None
+        depth = depth.to(dev).contiguous().float() if need_depth else None
+        B, C, H, W = (img if need_img else depth).shape
+        assert C == 3 and (img is None or depth is None or depth.shape == img.shape), \
+            "expects [B,3,H,W] image and XYZ tensors"
         self._ensure_native(dev)
         L = _native.lib()
         embed = torch.empty((B, H * W, 64), dtype=torch.float32, device=dev)
@@ -179,5 +190,12 @@ def update_model(model, data):
 def seg_resnet34_8s_embedding(num_classes=2, num_units=64, data=None):
     """SEG.py:173-176."""
     model = SEGNET(in_channels=3, network_name="Resnet34_8s", num_units=num_units)
+    update_model(model, data)
+    return model
+
+
+def seg_resnet34_8s_embedding_early(num_classes=2, num_units=64, data=None):
+    """SEG.py:178-181 (needs cfg.INPUT='RGBD', cfg.TRAIN.FUSION_TYPE='early')."""
+    model = SEGNET(in_channels=6, network_name="Resnet34_8s", num_units=num_units)
     update_model(model, data)
     return model

@@ -141,8 +141,9 @@ def resnet34_8s_param_shapes(num_units: int = 64, in_channels: int = 3):
     return out
 
 
-def synthetic_state_dict(seed: int, num_units: int = 64, branches=("fcn", "fcn_depth")):
-    """Deterministic synthetic weights for the two-branch RGB-D net, as numpy arrays.
+def synthetic_state_dict(seed: int, num_units: int = 64, branches=("fcn", "fcn_depth"), in_channels: int = 3):
+    """Deterministic synthetic weights for the two-branch RGB-D net, as numpy arrays
+    (branches=("fcn",) for the COLOR / DEPTH / early-fusion nets, in_channels=6 for early fusion).
 
     Conv weights: N(0, 2/(fan_in+fan_out)) (xavier-normal, what SEG.py:77-85 applies);
     BatchNorm: NON-trivial gamma/beta/running stats so that BN folding is exercised
@@ -152,7 +153,7 @@ def synthetic_state_dict(seed: int, num_units: int = 64, branches=("fcn", "fcn_d
     sd = {}
     for bidx, br in enumerate(branches):
         rng = np.random.default_rng(15485863 * seed + 101 * bidx + 5)
-        for name, shape in resnet34_8s_param_shapes(num_units):
+        for name, shape in resnet34_8s_param_shapes(num_units, in_channels):
             key = f"{br}.resnet34_8s.{name}"
             if name.endswith("num_batches_tracked"):
                 sd[key] = np.array(1, dtype=np.int64)
