@@ -76,3 +76,24 @@ def test_config_modes():
     finally:
         C.cfg.INPUT, C.cfg.TRAIN.FUSION_TYPE = saved
     assert C.network_mode() == "RGBD_ADD"
+
+
+def test_cfg_from_file(tmp_path):
+    """Experiment ymls of the reference's experiments/cfgs/ layout (incl. !!python/tuple tags and many keys
+    this path never reads) merge into cfg; type mismatches and unsupported settings raise."""
+    saved = (C.cfg.INPUT, C.cfg.TRAIN.FUSION_TYPE, C.cfg.TRAIN.EMBEDDING_ALPHA, C.cfg.TEST.VISUALIZE)
+    y = tmp_path / "exp.yml"
+    y.write_text("EXP_DIR: tabletop_object\nINPUT: RGBD\nTRAIN:\n  MILESTONES: !!python/tuple [3]\n  FUSION_TYPE: early\n"
+                 "  SYN_CROP_SIZE: 224\n  EMBEDDING_METRIC: cosine\n  EMBEDDING_ALPHA: 0.03\nTEST:\n  VISUALIZE: True\n")
+    try:
+        C.cfg_from_file(str(y))
+        assert C.network_mode() == "RGBD_EARLY" and C.cfg.TRAIN.EMBEDDING_ALPHA == 0.03 and C.cfg.TEST.VISUALIZE is True
+        y.write_text("TRAIN:\n  SYN_CROP_SIZE: big\n")
+        with pytest.raises(ValueError):
+            C.cfg_from_file(str(y))
+        y.write_text("TRAIN:\n  EMBEDDING_METRIC: euclidean\n")
+        with pytest.raises(NotImplementedError):
+            C.cfg_from_file(str(y))
+    finally:
+        C.cfg.TRAIN.EMBEDDING_METRIC = "cosine"
+        C.cfg.INPUT, C.cfg.TRAIN.FUSION_TYPE, C.cfg.TRAIN.EMBEDDING_ALPHA, C.cfg.TEST.VISUALIZE = saved

@@ -73,3 +73,33 @@ def require_supported():
     network_mode()
     if not cfg.TRAIN.EMBEDDING_NORMALIZATION:
         raise NotImplementedError("EMBEDDING_NORMALIZATION=False is not implemented")
+
+
+def _merge(src: dict, dst: AttrDict, path=""):
+    for k, v in src.items():
+        if k not in dst:
+            continue        # the reference's cfg has ~200 training / dataset keys this path never reads
+        if isinstance(dst[k], AttrDict):
+            if not isinstance(v, dict):
+                raise ValueError("Type mismatch for config key: %s%s" % (path, k))
+            _merge(v, dst[k], path + k + ".")
+        else:
+            if dst[k] is not None and not isinstance(dst[k], np.ndarray) and type(dst[k]) is not type(v):
+                raise ValueError("Type mismatch (%s vs. %s) for config key: %s%s" % (type(dst[k]), type(v), path, k))
+            dst[k] = v
+
+
+def cfg_from_file(filename):
+    """config.py:436-442: merge an experiment yml (experiments/cfgs/*.yml) into `cfg`.  Keys the inference
+    path does not read are ignored; the `!!python/tuple` tags those files carry are accepted.  Unlike the
+    reference's `yaml.load` without a Loader this never constructs arbitrary Python objects."""
+    import yaml
+
+    class Loader(yaml.SafeLoader):
+        pass
+
+    Loader.add_constructor("tag:yaml.org,2002:python/tuple", lambda l, n: tuple(l.construct_sequence(n)))
+    with open(filename, "r") as f:
+        data = yaml.load(f, Loader=Loader) or {}
+    _merge(data, cfg)
+    require_supported()
