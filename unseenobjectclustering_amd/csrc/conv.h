@@ -21,7 +21,7 @@ struct ConvParams {
 int launch_conv(const ConvParams &p, hipStream_t st);
 
 // Winograd F(2x2,3x3) path (csrc/wino.hip) for 3x3 stride-1 layers: U = transformed weights
-// [G][16][Cout][Cin] (launch_wino_weights), Vws = scratch of wino_v_floats() floats.
+// [G][16][Cin/32][Cout][32] (launch_wino_weights), Vws = scratch of wino_v_floats() floats.
 bool wino_eligible(const ConvParams &p);
 size_t wino_v_floats(int G, int B, int H, int W, int d, int Cin);
 int launch_wino_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st);

@@ -23,7 +23,7 @@ struct ConvLayer {
   int Cin, Cout, K, stride, dil, pad, relu;
   bool has_bn, has_bias, stem;
   float *d_w = nullptr, *d_b = nullptr;  // [G][...]
-  float *d_U = nullptr;                  // Winograd-transformed weights [G][16][Cout][Cin] (eligible layers only)
+  float *d_U = nullptr;                  // Winograd-transformed weights [G][16][Cin/32][Cout][32] (eligible layers only)
   size_t w_per_group = 0;
 };
 
@@ -215,7 +215,7 @@ static NetWs carve_net(void *base, int mode, int B, int H, int W) {
   if (a3 > act) act = a3;
   for (int i = 0; i < 4; ++i) w.buf[i] = take(act);
   w.fc = take((size_t)G * B * d.H3 * d.W3 * 64);
-  // Winograd scratch V[G][16][tiles][Cin]: worst case over the layers that may use it (1/8 resolution,
+  // Winograd scratch V[G][16][Cin/32][tiles][32]: worst case over the layers that may use it (1/8 resolution,
   // dilation 2 with 256 channels or dilation 4 with 512 channels; also sized for 1/4 resolution x 64)
   size_t wv = wino_v_floats(G, B, d.H3, d.W3, 4, 512);
   const size_t wv3 = wino_v_floats(G, B, d.H3, d.W3, 2, 256), wv2 = wino_v_floats(G, B, d.H3, d.W3, 1, 128),

@@ -9,8 +9,8 @@
 //
 // Three kernels (csrc/net.hip decides per layer; results differ from the direct kernel only by fp32
 // rounding, ~1e-6 relative):
-//   wino_weight_kernel  U[g][xi][cout][cin] = G g G^T           once, at uoc_net_finalize
-//   wino_input_kernel   V[g][xi][tile][cin] = B^T d B           elementwise, NHWC float4
+//   wino_weight_kernel  U[g][xi][cin/32][cout][32] = G g G^T    once, at uoc_net_finalize
+//   wino_input_kernel   V[g][xi][cin/32][tile][32] = B^T d B    elementwise, NHWC float4
 //   wino_gemm_kernel    M_xi = U_xi V_xi^T on v_mfma_f32_16x16x4_f32, the OUTPUT transform folded in:
 //     8 waves = 2 frequency groups (xi 0-7 / 8-15) x 4 groups of 16 output channels; a group walks its
 //     8 frequencies one after the other (K order: frequency outer, cin inner), and after the last cin
@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float *__restric
       const float u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
       const float u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
       const float u3 = t[a][2];
-      const size_t o = (((size_t)g * 16 + a * 4) * Cout + co) * Cin + ci;
+      // chunk-major: U[g][xi][cin / 32][cout][32] — the rows of one (frequency, cin chunk) are contiguous
+      const size_t o = ((((size_t)g * 16 + a * 4) * (Cin / WBK) + ci / WBK) * Cout + co) * WBK + ci % WBK;
       const size_t s = (size_t)Cout * Cin;
       U[o] = u0;
       U[o + s] = u1;
@@ -128,8 +129,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
       t[2][j] = f4sub(dd[2][j], dd[1][j]);
       t[3][j] = f4sub(dd[1][j], dd[3][j]);
     }
+    // chunk-major: V[g][xi][cin / 32][tile][32]: a block's rows of one (frequency, cin chunk) are one
+    // contiguous run, so consecutive rows fall into consecutive L2 channels (with [tile][cin] rows every
+    // row of a chunk is Cin*4 bytes apart and a 512-channel layer hits ONE of the 16 channels per XCD)
     const size_t plane = (size_t)geo.NT * C;
-    float *dst = V + ((size_t)g * 16 * geo.NT + tau) * C + 4 * c4;
+    float *dst = V + (size_t)g * 16 * plane + ((size_t)(c4 >> 3) * geo.NT + tau) * WBK + 4 * (c4 & 7);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       *reinterpret_cast<float4 *>(dst + (size_t)(4 * i + 0) * plane) = f4sub(t[i][0], t[i][2]);
@@ -167,7 +171,14 @@ __device__ __forceinline__ f32x4 wmfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int TMT>
+// VARIANT != 0: timing ablations only (wrong results; UOC_WINO_VARIANT, dev): 1 = no DMA in the loop,
+// 4 = full, but every chunk re-reads chunk 0 (same LDS traffic, all cache hits).  Measured on MI355X, layer4 at
+// TMT = 5: full 207 us, no DMA 170 us, DMA from cache-resident rows 183 us, MFMA + fold alone 156 us
+// (= 70 % matrix-pipe busy in the full kernel, SQ_VALU_MFMA_BUSY_CYCLES).  What did NOT move the 37 us the
+// L2-sourced DMA costs: a 4-deep ring (NSTG = 4; so it is not latency), two dedicated producer waves issuing
+// all DMA (so it is not MFMA waves stalling on DMA issue), chunk-major U / V (-2 %), fewer L2 misses through
+// the XCD mapping (0 %).
+template <int TMT, int NSTG, int VARIANT = 0>
 __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
                                                         const float *__restrict__ bias_, const float *__restrict__ res_,
                                                         float *__restrict__ out_, WinoGeom geo, int G, int Cin, int Cout,
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
   constexpr int RPP = 64;           // 8 waves x 8 rows per DMA pass
   constexpr int NPASS = (R + RPP - 1) / RPP;
   constexpr int STAGE = R * WBK;
-  static_assert(SEG % 16 == 0 && NPASS <= 8, "tile shape");
+  static_assert(SEG % 16 == 0 && NPASS <= 8 && NSTG >= 3 && NSTG <= 4, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -186,13 +197,15 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
   const int per_xcd = (total + 7) >> 3;
   const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (work >= total) return;
+  // tile-row outer, channel-tile inner: the blocks that share an XCD's L2 cover a few tile rows x ALL channel
+  // tiles, which minimises the distinct U + V rows the XCD pulls in per chunk (layer4: 208 KB instead of 352 KB)
   const int g = work / (ntiles * mtiles);
   const int rem = work - g * (ntiles * mtiles);
-  const int nt = rem / mtiles, mt = rem - nt * mtiles;
+  const int mt = rem / ntiles, nt = rem - mt * ntiles;
   const int m0 = mt * BM, n0 = nt * WBN;
   const int NT = geo.NT;
   const int cpt = Cin / WBK;
-  const int nit = 8 * cpt;
+  const int nit = 8 * cpt;  // >= 8 > NSTG
 
   const float *zero = reinterpret_cast<const float *>(g_wino_zero);
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char *)smem);
@@ -202,9 +215,11 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
   const int t = lane & 15, q = lane >> 4;
 
   // ---- DMA descriptors ---------------------------------------------------------------------------
-  int d_r0[NPASS], d_off[NPASS], d_kind[NPASS];  // kind: bit0 = U row, bit1 = frequency group, 4 = zero page
+  constexpr int NISS = NPASS;  // DMA instructions per wave and chunk: 8 waves x 8 rows per pass
+  static_assert((NSTG - 1) * NISS < 64, "vmcnt range");
+  int d_r0[NISS], d_off[NISS], d_kind[NISS];  // kind: bit0 = U row, bit1 = frequency group, 4 = zero page
 #pragma unroll
-  for (int j = 0; j < NPASS; ++j) {
+  for (int j = 0; j < NISS; ++j) {
     int r0 = j * RPP + wave * 8;
     if (r0 >= R) r0 = R - 8;
     d_r0[j] = r0;
@@ -214,36 +229,44 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
     const int rr = r - fr * SEG;
     if (rr >= BM) {
       d_kind[j] = 1 | (fr << 1);
-      d_off[j] = (n0 + rr - BM) * Cin + 4 * c;
+      d_off[j] = (n0 + rr - BM) * WBK + 4 * c;
     } else {
       const int tau = m0 + rr;
       d_kind[j] = (tau < NT) ? (fr << 1) : 4;
-      d_off[j] = tau * Cin + 4 * c;
+      d_off[j] = tau * WBK + 4 * c;
     }
   }
-  // running (frequency-pair e, cin offset c0) of the chunk being issued
-  int q_e = 0, q_c0 = 0;
+  // running (frequency-pair e, cin chunk cc) of the chunk being issued
+  int q_e = 0, q_cc = 0;
 #define W_ISSUE(STG)                                                                                    \
   {                                                                                                     \
     /* four wave-uniform row bases (U / V plane of each frequency group) for this chunk; the per-lane  \
        part of an address is a select + a 32-bit offset add */                                          \
-    const size_t pl0_ = (size_t)(g * 16 + q_e), pl1_ = pl0_ + 8;                                        \
-    const float *bu0_ = U + pl0_ * Cout * Cin + q_c0, *bu1_ = U + pl1_ * Cout * Cin + q_c0;             \
-    const float *bv0_ = V + pl0_ * NT * Cin + q_c0, *bv1_ = V + pl1_ * NT * Cin + q_c0;                 \
-    _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                                 \
+    const size_t ch0_ = VARIANT == 4 ? 0 : (size_t)(g * 16 + q_e) * cpt + q_cc, ch1_ = ch0_ + 8 * cpt;  \
+    const float *bu0_ = U + ch0_ * Cout * WBK, *bu1_ = U + ch1_ * Cout * WBK;                           \
+    const float *bv0_ = V + ch0_ * NT * WBK, *bv1_ = V + ch1_ * NT * WBK;                               \
+    _Pragma("unroll") for (int j = 0; j < NISS; ++j) {                                                  \
       const int kd = d_kind[j];                                                                         \
       const float *b_ = (kd & 1) ? ((kd & 2) ? bu1_ : bu0_) : ((kd & 2) ? bv1_ : bv0_);                 \
       const float *src = (kd & 4) ? zero : b_ + d_off[j];                                               \
       wglds16(src, lds_base + (unsigned)(((STG)*STAGE + d_r0[j] * WBK) * sizeof(float)));               \
     }                                                                                                   \
+    if (++q_cc == cpt) {                                                                                \
+      q_cc = 0;                                                                                         \
+      ++q_e;                                                                                            \
+    }                                                                                                   \
   }
-#define W_ADVANCE()          \
-  {                          \
-    q_c0 += WBK;             \
-    if (q_c0 == Cin) {       \
-      q_c0 = 0;              \
-      ++q_e;                 \
-    }                        \
+  // before the barrier of step `it`: chunk it+1 must have landed; younger chunks (up to NSTG-2 of them) may fly
+#define W_WAIT_NEXT(IT)                                \
+  {                                                    \
+    if (VARIANT == 1)                                  \
+      wwait_vmcnt<0>();                                \
+    else if (NSTG == 4 && (IT) + 3 < nit)              \
+      wwait_vmcnt<2 * NISS>();                         \
+    else if ((IT) + 2 < nit)                           \
+      wwait_vmcnt<NISS>();                             \
+    else                                               \
+      wwait_vmcnt<0>();                                \
   }
 #define W_FRAG(STG, HH, WA, XB)                                                                            \
   {                                                                                                        \
@@ -265,66 +288,66 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
   }
 
   float4 wa0, wa1, xb0[TMT], xb1[TMT];
+  // prologue: chunks 0 .. NSTG-2 into stages 0 .. NSTG-2
   W_ISSUE(0)
-  W_ADVANCE()
-  if (nit > 1) {
-    W_ISSUE(1)
-    W_ADVANCE()
-    wwait_vmcnt<NPASS>();
-  } else {
-    wwait_vmcnt<0>();
+  W_ISSUE(1)
+  if (NSTG == 4) W_ISSUE(2)
+  wwait_vmcnt<(NSTG - 2) * NISS>();  // chunk 0 has landed
+  // stage of chunk it-1 (= of chunk it+NSTG-1, the one issued during step it), of chunk it, of chunk it+1
+  int s_prev = NSTG - 1, s_cur = 0, s_nxt = 1;
+#define W_ROTATE()                               \
+  {                                              \
+    s_prev = s_cur;                              \
+    s_cur = s_nxt;                               \
+    s_nxt = s_nxt + 1 == NSTG ? 0 : s_nxt + 1;   \
   }
-  __builtin_amdgcn_s_barrier();
-  W_FRAG(0, 0, wa0, xb0)
-  int s_cur = 0, s_nxt = 1, s_nn = 2;
-  int cc = 0, e_cur = 0;  // cin chunk / frequency-pair of the chunk being multiplied
-  const bool early = wave < 4;
-  for (int it = 0; it < nit; ++it) {
-    if (it + 2 < nit && early) W_ISSUE(s_nn)
-    W_MFMA_E(wa0, xb0, x)
-    W_FRAG(s_cur, 1, wa1, xb1)
-    __builtin_amdgcn_sched_barrier(0);
-    W_MFMA_E(wa0, xb0, y)
-    W_MFMA_E(wa0, xb0, z)
-    W_MFMA_E(wa0, xb0, w)
-    if (it + 2 < nit && !early) W_ISSUE(s_nn)
-    if (it + 2 < nit) W_ADVANCE()
-    if (it + 2 < nit)
-      wwait_vmcnt<NPASS>();
-    else
-      wwait_vmcnt<0>();
-    __builtin_amdgcn_s_waitcnt(0xC07F);
+  {
     __builtin_amdgcn_s_barrier();
-    if (it + 1 < nit) W_FRAG(s_nxt, 0, wa0, xb0)
-    __builtin_amdgcn_sched_barrier(0);
-    W_MFMA_E(wa1, xb1, x)
-    W_MFMA_E(wa1, xb1, y)
-    W_MFMA_E(wa1, xb1, z)
-    W_MFMA_E(wa1, xb1, w)
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_sched_barrier(0);
-    if (++cc == cpt) {  // frequency xi = 8f + e_cur is complete: fold it into the four output accumulators
-      cc = 0;
-      const int xi = 8 * f + e_cur;
-      ++e_cur;
-      const float c0 = c_wino_y[xi][0], c1 = c_wino_y[xi][1], c2 = c_wino_y[xi][2], c3 = c_wino_y[xi][3];
+    W_FRAG(0, 0, wa0, xb0)
+    int cc = 0, e_cur = 0;  // cin chunk / frequency-pair of the chunk being multiplied
+    const bool early = wave < 4;
+    for (int it = 0; it < nit; ++it) {
+      const bool more = it + NSTG - 1 < nit && VARIANT != 1;
+      if (more && early) W_ISSUE(s_prev)
+      W_MFMA_E(wa0, xb0, x)
+      W_FRAG(s_cur, 1, wa1, xb1)
+      __builtin_amdgcn_sched_barrier(0);
+      W_MFMA_E(wa0, xb0, y)
+      W_MFMA_E(wa0, xb0, z)
+      W_MFMA_E(wa0, xb0, w)
+      if (more && !early) W_ISSUE(s_prev)
+      W_WAIT_NEXT(it)
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      if (it + 1 < nit) W_FRAG(s_nxt, 0, wa0, xb0)
+      __builtin_amdgcn_sched_barrier(0);
+      W_MFMA_E(wa1, xb1, x)
+      W_MFMA_E(wa1, xb1, y)
+      W_MFMA_E(wa1, xb1, z)
+      W_MFMA_E(wa1, xb1, w)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      if (++cc == cpt) {  // frequency xi = 8f + e_cur is complete: fold it into the four output accumulators
+        cc = 0;
+        const int xi = 8 * f + e_cur;
+        ++e_cur;
+        const float c0 = c_wino_y[xi][0], c1 = c_wino_y[xi][1], c2 = c_wino_y[xi][2], c3 = c_wino_y[xi][3];
 #pragma unroll
-      for (int i = 0; i < TMT; ++i) {
-        Y[0][i] += c0 * M[i];
-        Y[1][i] += c1 * M[i];
-        Y[2][i] += c2 * M[i];
-        Y[3][i] += c3 * M[i];
-        M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < TMT; ++i) {
+          Y[0][i] += c0 * M[i];
+          Y[1][i] += c1 * M[i];
+          Y[2][i] += c2 * M[i];
+          Y[3][i] += c3 * M[i];
+          M[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
       }
+      W_ROTATE()
     }
-    const int tmp = s_cur;
-    s_cur = s_nxt;
-    s_nxt = s_nn;
-    s_nn = tmp;
   }
+#undef W_ROTATE
+#undef W_WAIT_NEXT
 #undef W_ISSUE
-#undef W_ADVANCE
 #undef W_FRAG
 #undef W_MFMA_E
 
@@ -378,20 +401,21 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
   }
 }
 
-template <int TMT>
+template <int TMT, int NSTG, int VARIANT = 0>
 static int launch_wino_gemm(const ConvParams &p, const float *U, const float *V, const WinoGeom &geo, hipStream_t st) {
   constexpr int BM = 16 * TMT;
   const int mtiles = (geo.NT + BM - 1) / BM, ntiles = p.Cout / WBN;
-  const size_t lds = (size_t)3 * 2 * (BM + WBN) * WBK * sizeof(float);
+  const size_t lds = (size_t)NSTG * 2 * (BM + WBN) * WBK * sizeof(float);
+  static_assert((size_t)NSTG * 2 * (BM + WBN) * WBK * sizeof(float) <= 160 * 1024, "LDS ring too large");
   static bool attr_set = false;
   if (!attr_set) {
-    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_gemm_kernel<TMT>),
+    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_gemm_kernel<TMT, NSTG, VARIANT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   const int total = mtiles * ntiles * p.G;
-  hipLaunchKernelGGL((wino_gemm_kernel<TMT>), dim3(((total + 7) / 8) * 8), dim3(512), lds, st, V, U, p.bias, p.res, p.out,
-                     geo, p.G, p.Cin, p.Cout, p.relu, ntiles, mtiles);
+  hipLaunchKernelGGL((wino_gemm_kernel<TMT, NSTG, VARIANT>), dim3(((total + 7) / 8) * 8), dim3(512), lds, st,
+                     V, U, p.bias, p.res, p.out, geo, p.G, p.Cin, p.Cout, p.relu, ntiles, mtiles);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
 }
@@ -430,10 +454,11 @@ int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_
   const int ntiles = p.Cout / WBN;
   int best = 5;
   double best_cost = -1;
-  for (int tmt = 4; tmt <= 7; ++tmt) {
+  for (int tmt = 2; tmt <= 7; ++tmt) {
     const long blocks = (long)((geo.NT + 16 * tmt - 1) / (16 * tmt)) * ntiles * p.G;
     const long rounds = (blocks + 255) / 256;
-    const double cost = (double)rounds * tmt * (1.0 + 0.04 * (7.0 / tmt - 1.0));
+    // measured per-unit cost (MI355X, scripts/wino_microbench.py): flat from 4 to 7 tile rows, +20 % for 2 and 3
+    const double cost = (double)rounds * tmt * (tmt <= 3 ? 1.2 : 1.0);
     if (best_cost < 0 || cost <= best_cost) {
       best = tmt;
       best_cost = cost;
@@ -442,11 +467,24 @@ int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_
   const double M = (double)p.B * p.H * p.W;
   ProfScope prof(KC_WINO_GEMM, st, 2.0 * M * p.Cout * p.Cin * 9.0 * p.G,
                  4.0 * p.G * (16.0 * geo.NT * p.Cin + 16.0 * p.Cout * p.Cin + M * p.Cout * (p.res ? 2 : 1)));
+  if (const char *e = getenv("UOC_WINO_TMT")) {  // dev: force the tile height
+    const int v = atoi(e);
+    if (v >= 2 && v <= 7) best = v;
+  }
+  if (const char *e = getenv("UOC_WINO_VARIANT")) {  // dev: timing ablations of the TMT=5 kernel
+    switch (atoi(e)) {
+      case 1: return launch_wino_gemm<5, 3, 1>(p, U, Vws, geo, st);
+      case 4: return launch_wino_gemm<5, 3, 4>(p, U, Vws, geo, st);
+      default: break;
+    }
+  }
   switch (best) {
-    case 4: return launch_wino_gemm<4>(p, U, Vws, geo, st);
-    case 6: return launch_wino_gemm<6>(p, U, Vws, geo, st);
-    case 7: return launch_wino_gemm<7>(p, U, Vws, geo, st);
-    default: return launch_wino_gemm<5>(p, U, Vws, geo, st);
+    case 2: return launch_wino_gemm<2, 3>(p, U, Vws, geo, st);
+    case 3: return launch_wino_gemm<3, 3>(p, U, Vws, geo, st);
+    case 4: return launch_wino_gemm<4, 3>(p, U, Vws, geo, st);
+    case 6: return launch_wino_gemm<6, 3>(p, U, Vws, geo, st);
+    case 7: return launch_wino_gemm<7, 3>(p, U, Vws, geo, st);
+    default: return launch_wino_gemm<5, 3>(p, U, Vws, geo, st);
   }
 }
 
