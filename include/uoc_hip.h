@@ -75,6 +75,14 @@ int uoc_ms_cluster(const float *d_X, int batch, int n, int m, float kappa, int i
                    const int32_t *d_first_index, int32_t *d_labels, int32_t *d_indices,
                    float *d_Z_out, int32_t *d_seed_labels_out, void *d_ws, size_t ws_bytes, void *stream);
 
+/* 128-d embeddings (cfg.TRAIN.FUSION_TYPE = 'cat', SEG.py:109-110): the field is stored as `halves` = 2 planes of 64
+ * channels, d_X [batch][halves][n][64] (plane 0 = channels 0..63), and so are the converged seeds d_Z_out
+ * [batch][halves][m][64]; every dot product runs over both planes.  halves = 1 is exactly uoc_ms_cluster. */
+size_t uoc_ms_workspace_bytes_wide(int batch, int n, int m, int halves);
+int uoc_ms_cluster_wide(const float *d_X, int halves, int batch, int n, int m, float kappa, int iters, float epsilon,
+                        const int32_t *d_first_index, int32_t *d_labels, int32_t *d_indices, float *d_Z_out,
+                        int32_t *d_seed_labels_out, void *d_ws, size_t ws_bytes, void *stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * RGB-D ResNet34-8s embedding network — replaces SEGNET.forward (lib/networks/SEG.py:88-119,
@@ -88,11 +96,12 @@ typedef struct uoc_net uoc_net;
  *   COLOR      cfg.INPUT='COLOR'                     : fcn(img)
  *   DEPTH      cfg.INPUT='DEPTH'                     : fcn(xyz)   (the weights still live under "fcn.")
  *   RGBD_EARLY cfg.INPUT='RGBD', FUSION_TYPE='early' : fcn(cat(img, xyz)), a 6-channel stem (SEG.py:178-181)
- * FUSION_TYPE='cat' (128-d embeddings) is not implemented. */
-enum { UOC_NET_RGBD_ADD = 0, UOC_NET_COLOR = 1, UOC_NET_DEPTH = 2, UOC_NET_RGBD_EARLY = 3 };
+ *   RGBD_CAT   cfg.INPUT='RGBD', FUSION_TYPE='cat'   : cat(fcn(img), fcn_depth(xyz)) -> 128-d embeddings (:109-110) */
+enum { UOC_NET_RGBD_ADD = 0, UOC_NET_COLOR = 1, UOC_NET_DEPTH = 2, UOC_NET_RGBD_EARLY = 3, UOC_NET_RGBD_CAT = 4 };
 
 int uoc_net_create(uoc_net **out);                   /* = uoc_net_create_mode(out, UOC_NET_RGBD_ADD) */
 int uoc_net_create_mode(uoc_net **out, int mode);
+int uoc_net_embed_dim(const uoc_net *net);           /* 64, or 128 for RGBD_CAT */
 int uoc_net_destroy(uoc_net *net);
 /* One state-dict entry by its reference key ("fcn.resnet34_8s.layer1.0.conv1.weight", ...;
  * SEG.py:130-159 contract), HOST fp32 memory, copied. */
@@ -103,7 +112,8 @@ int uoc_net_finalize(uoc_net *net);
 size_t uoc_net_workspace_bytes(const uoc_net *net, int B, int H, int W);
 /* d_rgb, d_xyz: [B][3][H][W] fp32 NCHW (what test_sample hands the network, test_dataset.py:247);
  * the one the mode does not read (d_xyz for COLOR, d_rgb for DEPTH) may be NULL.
- * d_embed: [B][H*W][64] pixel-major unit-norm embeddings. */
+ * d_embed: [B][H*W][64] pixel-major unit-norm embeddings; RGBD_CAT: [B][2][H*W][64], plane 0 = the image
+ * branch's 64 channels, plane 1 = the XYZ branch's, normalised over all 128 (the layout uoc_ms_cluster_wide reads). */
 int uoc_net_forward(uoc_net *net, const float *d_rgb, const float *d_xyz, int B, int H, int W, float *d_embed,
                     void *d_ws, size_t ws_bytes, void *stream);
 

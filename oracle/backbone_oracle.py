@@ -60,12 +60,13 @@ def resnet34_8s(sd, pfx, x):
 
 def segnet_forward(sd, img, depth, mode="RGBD_ADD"):
     """SEG.py:97-114 -> [B,64,H,W] unit-norm.  mode: 'RGBD_ADD' normalize(fcn(img) + fcn_depth(depth)) (:106-108),
-    'COLOR' fcn(img) (:100), 'DEPTH' fcn(depth) (:98), 'RGBD_EARLY' fcn(cat(img, depth)) (:102-103)."""
+    'COLOR' fcn(img) (:100), 'DEPTH' fcn(depth) (:98), 'RGBD_EARLY' fcn(cat(img, depth)) (:102-103),
+    'RGBD_CAT' normalize(cat(fcn(img), fcn_depth(depth))) -> [B,128,H,W] (:109-110)."""
     with torch.no_grad():
-        if mode == "RGBD_ADD":
+        if mode in ("RGBD_ADD", "RGBD_CAT"):
             _, a = resnet34_8s(sd, "fcn.resnet34_8s.", img)
             _, b = resnet34_8s(sd, "fcn_depth.resnet34_8s.", depth)
-            a = a + b
+            a = a + b if mode == "RGBD_ADD" else torch.cat((a, b), 1)            # :107-110
         elif mode == "COLOR":
             _, a = resnet34_8s(sd, "fcn.resnet34_8s.", img)
         elif mode == "DEPTH":

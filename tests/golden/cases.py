@@ -96,10 +96,17 @@ MODES = {
     "COLOR":      dict(INPUT="COLOR", FUSION="add",   factory="seg_resnet34_8s_embedding",       in_channels=3),
     "DEPTH":      dict(INPUT="DEPTH", FUSION="add",   factory="seg_resnet34_8s_embedding",       in_channels=3),
     "RGBD_EARLY": dict(INPUT="RGBD",  FUSION="early", factory="seg_resnet34_8s_embedding_early", in_channels=6),
+    "RGBD_CAT":   dict(INPUT="RGBD",  FUSION="cat",   factory="seg_resnet34_8s_embedding",       in_channels=3),
+}
+# 128-d clustering (the 'cat' embeddings): reference mean_shift_smart_init on 128-channel synthetic fields
+WIDE_MEANSHIFT_CASES = {
+    "wide_60x80":   dict(seed=21, H=60,  W=80,  num_objects=4, noise=0.05, m=100, iters=10),
+    "wide_224":     dict(seed=22, H=224, W=224, num_objects=5, noise=0.06, m=100, iters=10),
+    "wide_480x640": dict(seed=23, H=480, W=640, num_objects=6, noise=0.05, m=100, iters=10),
 }
 MODE_BACKBONE_CASES = {
-    "tiny_64x64":  dict(wseed=5, frames=[7], H=64, W=64, samples=0),
-    "odd_72x104":  dict(wseed=6, frames=[8, 9], H=72, W=104, samples=1024),
+    "tiny_64x64":  dict(wseed=5, frames=[7], H=64, W=64, samples=512),
+    "odd_72x104":  dict(wseed=6, frames=[8, 9], H=72, W=104, samples=512),
 }
 MODE_GLUE_CASES = ["normal_5", "border_8", "small_ragged"]       # GLUE_CASES re-run without depth (COLOR input)
 MODE_E2E_CASES = {"color_a": dict(seed=43, objects=4)}

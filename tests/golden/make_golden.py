@@ -21,7 +21,7 @@ sys.path.insert(0, HERE)
 
 import ref_harness  # noqa: E402
 from cases import (MEANSHIFT_CASES, KAPPA, EPSILON, RNG_SEED, BACKBONE_CASES, GLUE_CASES, E2E_CASES,  # noqa: E402
-                   MODES, MODE_BACKBONE_CASES, MODE_GLUE_CASES, MODE_E2E_CASES,
+                   MODES, MODE_BACKBONE_CASES, MODE_GLUE_CASES, MODE_E2E_CASES, WIDE_MEANSHIFT_CASES,
                    sample_positions, glue_inputs, crop_cluster_labels, e2e_stub_features)
 from unseenobjectclustering_amd import synth  # noqa: E402
 
@@ -162,11 +162,12 @@ def make_modes(ref):
         for mode, m in MODES.items():
             ref.cfg.INPUT, ref.cfg.TRAIN.FUSION_TYPE = m["INPUT"], m["FUSION"]
             for name, c in MODE_BACKBONE_CASES.items():
+                branches = ("fcn", "fcn_depth") if mode == "RGBD_CAT" else ("fcn",)
                 sd = {k: torch.from_numpy(np.asarray(v))
-                      for k, v in synth.synthetic_state_dict(c["wseed"], branches=("fcn",), in_channels=m["in_channels"]).items()}
+                      for k, v in synth.synthetic_state_dict(c["wseed"], branches=branches, in_channels=m["in_channels"]).items()}
                 with contextlib.redirect_stdout(io.StringIO()):
                     net = ref.networks.__dict__[m["factory"]](2, 64, sd).eval()
-                assert not hasattr(net, "fcn_depth")
+                assert hasattr(net, "fcn_depth") == (mode == "RGBD_CAT")
                 got = net.state_dict()
                 assert all(torch.equal(got[k], v) for k, v in sd.items()), "update_model dropped an entry"
                 frames = [synth.rgbd_frame(s_, c["H"], c["W"], 4) for s_ in c["frames"]]
@@ -175,7 +176,7 @@ def make_modes(ref):
                 with torch.no_grad():
                     feat = net(img, None, None if mode == "COLOR" else dep)
                 B = feat.shape[0]
-                flat = feat.permute(0, 2, 3, 1).reshape(B, -1, 64).numpy()
+                flat = feat.permute(0, 2, 3, 1).reshape(B, -1, feat.shape[1]).numpy()
                 key = f"{mode}/{name}"
                 if c["samples"]:
                     pos = sample_positions(99, flat.shape[1], c["samples"])
@@ -184,6 +185,24 @@ def make_modes(ref):
                 else:
                     out[key + "/embed"] = flat.astype(np.float32)
                 print(key, feat.shape, "norm check", float(feat.norm(dim=1).mean()), flush=True)
+
+        # 128-d clustering, the reference's mean_shift_smart_init stage by stage (as make_meanshift does for 64-d)
+        ms = ref.mean_shift
+        for name, c in WIDE_MEANSHIFT_CASES.items():
+            X, _ = synth.embedding_field(c["seed"], c["H"], c["W"], 128, c["num_objects"], c["noise"])
+            Xt = torch.from_numpy(X)
+            np.random.seed(RNG_SEED)
+            labels, idx = ms.mean_shift_smart_init(Xt, KAPPA, num_seeds=c["m"], max_iters=c["iters"], metric="cosine")
+            np.random.seed(RNG_SEED)
+            seeds, idx2 = ms.select_smart_seeds(Xt, c["m"], return_selected_indices=True, metric="cosine")
+            assert torch.equal(idx, idx2)
+            Z = ms.seed_hill_climbing_ball(Xt, seeds, KAPPA, max_iters=c["iters"], metric="cosine")
+            seed_labels = ms.connected_components(Z, 2 * ref.cfg.TRAIN.EMBEDDING_ALPHA, metric="cosine")
+            out[f"WIDE/{name}/labels"] = labels.numpy().astype(np.uint8)
+            out[f"WIDE/{name}/indices"] = idx.numpy().astype(np.int32)
+            out[f"WIDE/{name}/Z"] = Z.numpy().astype(np.float32)
+            out[f"WIDE/{name}/seed_labels"] = seed_labels.numpy().astype(np.int32)
+            print("WIDE", name, "clusters:", np.unique(labels.numpy()).tolist(), flush=True)
 
         ref.cfg.INPUT, ref.cfg.TRAIN.FUSION_TYPE = "COLOR", "add"
         for name in MODE_GLUE_CASES:

@@ -8,11 +8,14 @@ import pytest
 import torch
 
 from oracle import backbone_oracle as BO
+from oracle import mean_shift_oracle as MS
 from tests.golden.cases import (GLUE_CASES, MODES, MODE_BACKBONE_CASES, MODE_GLUE_CASES, MODE_E2E_CASES, RNG_SEED,
-                                glue_inputs, crop_cluster_labels, e2e_stub_features)
+                                WIDE_MEANSHIFT_CASES, KAPPA, EPSILON, glue_inputs, crop_cluster_labels,
+                                e2e_stub_features)
 from unseenobjectclustering_amd import networks, synth
 from unseenobjectclustering_amd.fcn import test_dataset as TD
 from unseenobjectclustering_amd.fcn.config import cfg
+from unseenobjectclustering_amd.utils import mean_shift as UMS
 
 pytestmark = pytest.mark.gpu
 EMBED_TOL = 1e-3
@@ -35,10 +38,11 @@ def mode_cfg():
 
 def _net(mode, wseed):
     m = MODES[mode]
+    branches = ("fcn", "fcn_depth") if mode == "RGBD_CAT" else ("fcn",)      # SEG.py:69-71
     sd = {k: torch.from_numpy(np.asarray(v))
-          for k, v in synth.synthetic_state_dict(wseed, branches=("fcn",), in_channels=m["in_channels"]).items()}
+          for k, v in synth.synthetic_state_dict(wseed, branches=branches, in_channels=m["in_channels"]).items()}
     net = networks.__dict__[m["factory"]](2, 64, sd).eval()
-    assert set(net.state_dict().keys()) == set(sd.keys())          # SEG.py:69-71: no fcn_depth branch
+    assert set(net.state_dict().keys()) == set(sd.keys())
     return net, sd
 
 
@@ -52,8 +56,9 @@ def test_network_modes_match_reference_golden(golden, device, mode_cfg, mode, na
     img = torch.from_numpy(np.concatenate([f["image_color"] for f in frames])).to(device)
     dep = torch.from_numpy(np.concatenate([f["depth"] for f in frames])).to(device)
     feat = net(img, None, None if mode == "COLOR" else dep)
-    assert feat.shape == (len(frames), 64, c["H"], c["W"])
-    flat = feat.permute(0, 2, 3, 1).reshape(len(frames), -1, 64).cpu().numpy()
+    dim = 128 if mode == "RGBD_CAT" else 64
+    assert feat.shape == (len(frames), dim, c["H"], c["W"])
+    flat = feat.permute(0, 2, 3, 1).reshape(len(frames), -1, dim).cpu().numpy()
     key = f"{mode}/{name}"
     if key + "/pos" in golden:
         flat = flat[:, golden[key + "/pos"]]
@@ -82,9 +87,6 @@ def test_mode_mismatch_raises(device, mode_cfg):
     mode_cfg("COLOR")
     with pytest.raises(ValueError):
         networks.seg_resnet34_8s_embedding_early(2, 64, None)
-    cfg.INPUT, cfg.TRAIN.FUSION_TYPE = "RGBD", "cat"
-    with pytest.raises(NotImplementedError):
-        networks.seg_resnet34_8s_embedding(2, 64, None)
     mode_cfg("DEPTH")
     net, _ = _net("DEPTH", 1)
     with pytest.raises(ValueError):
@@ -135,3 +137,61 @@ def test_test_sample_color_matches_reference_golden(golden, device, mode_cfg, na
     assert seen["depth"] is None and seen["depth_crop"] is None
     assert np.array_equal(out_label.numpy().astype(np.uint8), golden[f"COLOR/{name}/out_label"])
     assert np.array_equal(refined.numpy().astype(np.uint8), golden[f"COLOR/{name}/refined"])
+
+
+@pytest.mark.parametrize("name", list(WIDE_MEANSHIFT_CASES))
+def test_cluster_128d_matches_reference_golden(golden, device, name):
+    """128-d fields (the 'cat' embeddings) through uoc_ms_cluster_wide: seed indices and label maps bit-exact
+    against the reference's mean_shift_smart_init, converged seeds within 1e-4."""
+    c = WIDE_MEANSHIFT_CASES[name]
+    X, _ = synth.embedding_field(c["seed"], c["H"], c["W"], 128, c["num_objects"], c["noise"])
+    Xd = torch.from_numpy(X).to(device)
+    first = int(golden[f"WIDE/{name}/indices"][0])
+    labels, idx, Z, sl = UMS.cluster_batch(UMS.to_planes(Xd[None]), [first], KAPPA, c["m"], c["iters"], EPSILON,
+                                           return_parts=True)
+    assert np.array_equal(idx[0].cpu().numpy(), golden[f"WIDE/{name}/indices"])
+    Zr = Z[0].permute(1, 0, 2).reshape(c["m"], 128).cpu().numpy()
+    assert np.abs(Zr - golden[f"WIDE/{name}/Z"]).max() < 1e-4
+    assert np.array_equal(sl[0].cpu().numpy(), golden[f"WIDE/{name}/seed_labels"])
+    assert MS.labels_equal_up_to_permutation(labels[0].cpu().numpy(), golden[f"WIDE/{name}/labels"])
+    assert np.array_equal(labels[0].cpu().numpy().astype(np.uint8), golden[f"WIDE/{name}/labels"])
+    # the reference-named entry point on the row-major [n,128] tensor, global RNG draw included
+    np.random.seed(RNG_SEED)
+    lab2, idx2 = UMS.mean_shift_smart_init(Xd, KAPPA, c["m"], c["iters"])
+    assert lab2.dtype == torch.int64 and np.array_equal(idx2.numpy().astype(np.int32), golden[f"WIDE/{name}/indices"])
+    assert np.array_equal(lab2.cpu().numpy().astype(np.uint8), golden[f"WIDE/{name}/labels"])
+
+
+def test_cat_two_stage_vs_oracle(device, mode_cfg):
+    """'cat' fusion end to end against the CPU oracle's test_sample: (1) the real 128-d network on a small frame,
+    (2) stub networks returning structured [B,128,h,w] fields so that stage 2 (crops, 128-d crop clustering,
+    matching, paste) runs with several objects."""
+    from oracle import glue_oracle as G
+    mode_cfg("RGBD_CAT")
+    cfg.device = device
+    net, sd = _net("RGBD_CAT", 11)
+    fr = synth.rgbd_frame(77, 128, 160, 3)
+    img, dep = torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"])
+    onet = lambda i, l, d: BO.segnet_forward(sd, i, d, "RGBD_CAT")
+    want_label, want_refined = G.test_sample(img, dep, onet, onet, np.random.RandomState(RNG_SEED))
+    np.random.seed(RNG_SEED)
+    out_label, refined = TD.test_sample(dict(image_color=img, depth=dep), net, net)
+    assert MS.labels_equal_up_to_permutation(out_label.numpy(), want_label.numpy())
+    assert (refined is None) == (want_refined is None)
+    if refined is not None:
+        assert MS.labels_equal_up_to_permutation(refined.numpy(), want_refined.numpy())
+
+    def field(seed, H, W, k):
+        X, _ = synth.embedding_field(seed, H, W, 128, k, 0.05)
+        return torch.from_numpy(X).view(H, W, 128).permute(2, 0, 1)[None].contiguous()
+    fr = synth.rgbd_frame(78, 240, 320, 3)
+    img, dep = torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"])
+    s1 = lambda i, l, d: field(78, 240, 320, 5)
+    s2 = lambda i, l, d: torch.cat([field(900 + k, 224, 224, 2 + k % 3) for k in range(i.shape[0])])
+    want_label, want_refined = G.test_sample(img, dep, s1, s2, np.random.RandomState(RNG_SEED))
+    np.random.seed(RNG_SEED)
+    out_label, refined = TD.test_sample(dict(image_color=img, depth=dep), lambda i, l, d: s1(i, l, d).to(device),
+                                        lambda i, l, d: s2(i, l, d).to(device))
+    assert want_refined is not None and int(want_refined.max()) >= 2
+    assert np.array_equal(out_label.numpy(), want_label.numpy())
+    assert np.array_equal(refined.numpy(), want_refined.numpy())

@@ -9,8 +9,10 @@ import torch
 
 from oracle import backbone_oracle as BO
 from oracle import glue_oracle as G
+from oracle import mean_shift_oracle as MS
 from tests.golden.cases import (GLUE_CASES, MODES, MODE_BACKBONE_CASES, MODE_GLUE_CASES, MODE_E2E_CASES, RNG_SEED,
-                                glue_inputs, crop_cluster_labels, e2e_stub_features)
+                                WIDE_MEANSHIFT_CASES, KAPPA, EPSILON, glue_inputs, crop_cluster_labels,
+                                e2e_stub_features)
 from unseenobjectclustering_amd import synth
 from unseenobjectclustering_amd.fcn import config as C
 
@@ -23,11 +25,13 @@ def golden(golden_dir):
 @pytest.mark.parametrize("mode", list(MODES))
 def test_backbone_oracle_modes_match_reference(golden, mode):
     c = MODE_BACKBONE_CASES["tiny_64x64"]
+    branches = ("fcn", "fcn_depth") if mode == "RGBD_CAT" else ("fcn",)
     sd = {k: torch.from_numpy(np.asarray(v))
-          for k, v in synth.synthetic_state_dict(c["wseed"], branches=("fcn",), in_channels=MODES[mode]["in_channels"]).items()}
+          for k, v in synth.synthetic_state_dict(c["wseed"], branches=branches, in_channels=MODES[mode]["in_channels"]).items()}
     fr = synth.rgbd_frame(c["frames"][0], c["H"], c["W"], 4)
     out = BO.segnet_forward(sd, torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"]), mode)
-    flat = out.permute(0, 2, 3, 1).reshape(1, -1, 64).numpy()
+    assert out.shape[1] == (128 if mode == "RGBD_CAT" else 64)
+    flat = out.permute(0, 2, 3, 1).reshape(1, -1, out.shape[1]).numpy()[:, golden[f"{mode}/tiny_64x64/pos"]]
     assert np.abs(flat - golden[f"{mode}/tiny_64x64/embed"]).max() < 1e-6
 
 
@@ -59,6 +63,17 @@ def test_test_sample_oracle_color_matches_reference(golden, name):
     assert np.array_equal(refined.numpy().astype(np.uint8), golden[f"COLOR/{name}/refined"])
 
 
+@pytest.mark.parametrize("name", ["wide_60x80", "wide_224"])
+def test_mean_shift_oracle_128d_matches_reference(golden, name):
+    """128-d fields ('cat' fusion): the oracle's clustering against the reference's own mean_shift_smart_init."""
+    c = WIDE_MEANSHIFT_CASES[name]
+    X, _ = synth.embedding_field(c["seed"], c["H"], c["W"], 128, c["num_objects"], c["noise"])
+    first = int(golden[f"WIDE/{name}/indices"][0])
+    labels, idx = MS.mean_shift_smart_init(torch.from_numpy(X), KAPPA, c["m"], c["iters"], first_index=first, epsilon=EPSILON)
+    assert np.array_equal(idx.numpy().astype(np.int32), golden[f"WIDE/{name}/indices"])
+    assert np.array_equal(labels.numpy().astype(np.uint8), golden[f"WIDE/{name}/labels"])
+
+
 def test_config_modes():
     """cfg.INPUT / FUSION_TYPE -> network mode; unsupported combinations raise (no silent fallback)."""
     saved = (C.cfg.INPUT, C.cfg.TRAIN.FUSION_TYPE)
@@ -67,9 +82,6 @@ def test_config_modes():
             C.cfg.INPUT, C.cfg.TRAIN.FUSION_TYPE = m["INPUT"], m["FUSION"]
             assert C.network_mode() == mode
             assert C.uses_depth() == (mode != "COLOR")
-        C.cfg.INPUT, C.cfg.TRAIN.FUSION_TYPE = "RGBD", "cat"
-        with pytest.raises(NotImplementedError):
-            C.require_supported()
         C.cfg.INPUT = "XYZ"
         with pytest.raises(NotImplementedError):
             C.require_supported()

@@ -32,6 +32,8 @@ int launch_nchw3_to_nhwc4(const float *in, float *out, int B, int H, int W, hipS
 // 3x3 s2 p1 max pooling, NHWC, C % 4 == 0; `n_img` images
 int launch_maxpool3x3s2(const float *in, float *out, int n_img, int H, int W, int C, int Ho, int Wo, hipStream_t st);
 // embed[b][p][:] = normalize(bilinear_up(a[b] + c[b]))  (align_corners=True), a,c: [B][h][w][64]; c may be null
-int launch_head(const float *fa, const float *fb, float *embed, int B, int h, int w, int H, int W, hipStream_t st);
+// cat != 0: no sum; embed [B][2][H*W][64] = the two branches as planes, normalised over all 128 channels
+int launch_head(const float *fa, const float *fb, float *embed, int B, int h, int w, int H, int W, int cat,
+                hipStream_t st);
 
 }  // namespace uoc

@@ -892,15 +892,73 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ fa,
   }
 }
 
-int launch_head(const float *fa, const float *fb, float *embed, int B, int h, int w, int H, int W, hipStream_t st) {
+// 'cat' fusion (SEG.py:109-110,113-114): embed[b][0][p][:] / embed[b][1][p][:] = the two upsampled branches divided
+// by the norm of their concatenation.
+__global__ __launch_bounds__(256) void head_cat_kernel(const float *__restrict__ fa, const float *__restrict__ fb,
+                                                       float *__restrict__ embed, int B, int h, int w, int H, int W,
+                                                       float sy, float sx) {
+  const int lane = threadIdx.x & 63;
+  const int t = lane & 15, g = lane >> 4;
+  const int HW = H * W;
+  const long total = (long)B * HW;
+  const long gw = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nw = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long p4 = gw * 4; p4 < total; p4 += nw * 4) {
+    const long pix = p4 + g;
+    if (pix >= total) continue;
+    const int b = (int)(pix / HW);
+    const int r = (int)(pix - (long)b * HW);
+    const int oy = r / W, ox = r - oy * W;
+    const float fy = sy * (float)oy, fx = sx * (float)ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const size_t base = (size_t)b * h * w * 64 + 4 * t;
+    float4 o[2];
+    float ss = 0.f;
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+      const float *f = br ? fb : fa;
+      const float4 v00 = *reinterpret_cast<const float4 *>(f + base + ((size_t)y0 * w + x0) * 64);
+      const float4 v01 = *reinterpret_cast<const float4 *>(f + base + ((size_t)y0 * w + x1) * 64);
+      const float4 v10 = *reinterpret_cast<const float4 *>(f + base + ((size_t)y1 * w + x0) * 64);
+      const float4 v11 = *reinterpret_cast<const float4 *>(f + base + ((size_t)y1 * w + x1) * 64);
+      o[br].x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+      o[br].y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+      o[br].z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+      o[br].w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+      ss = fmaf(o[br].x, o[br].x, ss);
+      ss = fmaf(o[br].y, o[br].y, ss);
+      ss = fmaf(o[br].z, o[br].z, ss);
+      ss = fmaf(o[br].w, o[br].w, ss);
+    }
+    ss = row16_sum(ss);
+    const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+      o[br].x *= inv;
+      o[br].y *= inv;
+      o[br].z *= inv;
+      o[br].w *= inv;
+      *reinterpret_cast<float4 *>(embed + (((size_t)b * 2 + br) * HW + r) * 64 + 4 * t) = o[br];
+    }
+  }
+}
+
+int launch_head(const float *fa, const float *fb, float *embed, int B, int h, int w, int H, int W, int cat,
+                hipStream_t st) {
   const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
   const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   const long total = (long)B * H * W;
   long blocks = (total / 4 + 3) / 4;  // 4 waves per block, 4 pixels per wave step
   if (blocks > 4096) blocks = 4096;
   if (blocks < 1) blocks = 1;
-  ProfScope prof(KC_HEAD, st, 0.0, 4.0 * 64 * ((double)total + (fb ? 2.0 : 1.0) * B * h * w));
-  hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fa, fb, embed, B, h, w, H, W, sy, sx);
+  ProfScope prof(KC_HEAD, st, 0.0, 4.0 * 64 * ((cat ? 2.0 : 1.0) * (double)total + (fb ? 2.0 : 1.0) * B * h * w));
+  if (cat)
+    hipLaunchKernelGGL(head_cat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fa, fb, embed, B, h, w, H, W, sy, sx);
+  else
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)blocks), dim3(256), 0, st, fa, fb, embed, B, h, w, H, W, sy, sx);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
 }

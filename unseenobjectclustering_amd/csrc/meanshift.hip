@@ -55,15 +55,19 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax v) {
 //   dmin = min(dmin, d), per-block argmax(dmin) -> partials for step s+1.
 // 16 lanes share one pixel row (float4 each => a wave reads 1 KiB contiguous per load).
 // -------------------------------------------------------------------------------------------
+// NH = number of 64-channel halves of an embedding (1: the 64-d fields of every shipped mode but 'cat';
+// 2: 128-d fields stored as two planes X[b][h][n][64], seeds / Z likewise [b][h][m][64]); a dot product
+// is the sum over the halves.
+template <int NH>
 __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
     const float *__restrict__ X, int n, int m, int step, const int *__restrict__ first_index,
     float *__restrict__ dmin, float *__restrict__ seeds, int *__restrict__ indices,
     const ArgMax *__restrict__ part_in, ArgMax *__restrict__ part_out) {
   const int b = blockIdx.y;
   const int nblk = gridDim.x;
-  X += (size_t)b * n * C;
+  X += (size_t)b * NH * n * C;
   dmin += (size_t)b * n;
-  seeds += (size_t)b * m * C;
+  seeds += (size_t)b * NH * m * C;
   indices += (size_t)b * m;
   part_in += (size_t)b * FPS_MAX_BLOCKS;
   part_out += (size_t)b * FPS_MAX_BLOCKS;
@@ -92,29 +96,42 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
   }
   if (blockIdx.x == 0) {
     if (tid == 0) indices[step] = cur;
-    if (tid < C) seeds[(size_t)step * C + tid] = X[(size_t)cur * C + tid];
+    if (tid < NH * C)
+      seeds[((size_t)(tid / C) * m + step) * C + tid % C] = X[((size_t)(tid / C) * n + cur) * C + tid % C];
   }
   if (step == m - 1) return;  // the distances to the last seed are never consumed (:174 uses [:, :i])
 
   const int t = lane & 15, g = lane >> 4;
-  const float4 sv = *reinterpret_cast<const float4 *>(X + (size_t)cur * C + 4 * t);
+  float4 sv[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) sv[h] = *reinterpret_cast<const float4 *>(X + ((size_t)h * n + cur) * C + 4 * t);
   ArgMax best = {-INFINITY, INT_MAX};
   const int nchunk = (n + 63) >> 6;
   for (int chunk = blockIdx.x * (FPS_THREADS / 64) + wave; chunk < nchunk; chunk += nblk * (FPS_THREADS / 64)) {
     const int base = chunk << 6;
-    float4 x[16];
+    float4 x[NH][16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int p = base + 4 * i + g;
-      x[i] = (p < n) ? *reinterpret_cast<const float4 *>(X + (size_t)p * C + 4 * t) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int p = base + 4 * i + g;
+        x[h][i] = (p < n) ? *reinterpret_cast<const float4 *>(X + ((size_t)h * n + p) * C + 4 * t)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     float mine = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      float s = x[i].x * sv.x;
-      s = fmaf(x[i].y, sv.y, s);
-      s = fmaf(x[i].z, sv.z, s);
-      s = fmaf(x[i].w, sv.w, s);
+      float s = x[0][i].x * sv[0].x;
+      s = fmaf(x[0][i].y, sv[0].y, s);
+      s = fmaf(x[0][i].z, sv[0].z, s);
+      s = fmaf(x[0][i].w, sv[0].w, s);
+#pragma unroll
+      for (int h = 1; h < NH; ++h) {
+        s = fmaf(x[h][i].x, sv[h].x, s);
+        s = fmaf(x[h][i].y, sv[h].y, s);
+        s = fmaf(x[h][i].z, sv[h].z, s);
+        s = fmaf(x[h][i].w, sv[h].w, s);
+      }
       s = row16_sum(s);
       if (t == i) mine = s;
     }
@@ -370,26 +387,30 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int ST>
+// NH = 2 (128-d fields as two 64-channel planes): S sums over both halves; the accumulators of one block
+// cover ONE half (blockIdx.z), so S is computed twice — the price of keeping the 64-d register tiling.
+template <int ST, int NH>
 __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__restrict__ X, int n,
                                                              const float *__restrict__ Z, int m, float kappa,
                                                              float *__restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float *Zs = smem;  // [ST*16][ZP]; later reused as the cross-wave reduction buffer
+  float *Zs = smem;  // [NH][ST*16][ZP]; later reused as the cross-wave reduction buffer
   const int b = blockIdx.y;
   const int nblk = gridDim.x;
-  X += (size_t)b * n * C;
-  Z += (size_t)b * m * C;
-  partial += ((size_t)b * nblk + blockIdx.x) * (ST * 16) * C;
+  const int hz = NH > 1 ? blockIdx.z : 0;  // the half this block accumulates
+  X += (size_t)b * NH * n * C;
+  Z += (size_t)b * NH * m * C;
+  partial += (((size_t)b * nblk + blockIdx.x) * NH + hz) * (ST * 16) * C;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = lane & 15, q = lane >> 4;
 
-  for (int i = tid; i < ST * 16 * (C / 4); i += HC_THREADS) {
-    const int row = i / (C / 4), c4 = i % (C / 4);
+  for (int i = tid; i < NH * ST * 16 * (C / 4); i += HC_THREADS) {
+    const int h = i / (ST * 16 * (C / 4)), j = i % (ST * 16 * (C / 4));
+    const int row = j / (C / 4), c4 = j % (C / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < m) v = *reinterpret_cast<const float4 *>(Z + (size_t)row * C + 4 * c4);
-    *reinterpret_cast<float4 *>(Zs + row * ZP + 4 * c4) = v;
+    if (row < m) v = *reinterpret_cast<const float4 *>(Z + ((size_t)h * m + row) * C + 4 * c4);
+    *reinterpret_cast<float4 *>(Zs + (h * ST * 16 + row) * ZP + 4 * c4) = v;
   }
   __syncthreads();
 
@@ -403,25 +424,26 @@ __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__rest
   const int stride = nblk * (HC_THREADS / 64);
   int tile = blockIdx.x * (HC_THREADS / 64) + wave;
 
-  float4 xa[4], xb[4];
-  auto load_tile = [&](int tl, float4(&a)[4], float4(&bb)[4]) {
+  float4 xa[NH * 4], xb[4];
+  auto load_tile = [&](int tl, float4(&a)[NH * 4], float4(&bb)[4]) {
     const int pa = tl * 16 + t;
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
-      a[v] = (tl < ntile && pa < n) ? *reinterpret_cast<const float4 *>(X + (size_t)pa * C + 16 * v + 4 * q)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int v = 0; v < NH * 4; ++v)
+      a[v] = (tl < ntile && pa < n)
+                 ? *reinterpret_cast<const float4 *>(X + ((size_t)(v >> 2) * n + pa) * C + 16 * (v & 3) + 4 * q)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int pb = tl * 16 + 4 * q + r;
-      bb[r] = (tl < ntile && pb < n) ? *reinterpret_cast<const float4 *>(X + (size_t)pb * C + 4 * t)
+      bb[r] = (tl < ntile && pb < n) ? *reinterpret_cast<const float4 *>(X + ((size_t)hz * n + pb) * C + 4 * t)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   load_tile(tile, xa, xb);
 
   for (; tile < ntile; tile += stride) {
-    float4 na[4], nb[4];
-    load_tile(tile + stride, na, nb);  // software prefetch of the wave's next tile
+    float4 na[NH * 4], nb[4];
+    if (NH == 1) load_tile(tile + stride, na, nb);  // software prefetch of the wave's next tile
     // Software pipeline over the seed tiles (3 stages, fully unrolled): in step i the 16-deep
     // DEPENDENT MFMA chain S_i = X Z_i^T is interleaved 1:1 with the 16 INDEPENDENT accumulate MFMAs of
     // tile i-2 (hides the 40-cycle dependent-accumulator latency), while exp() of tile i-1 runs on the
@@ -441,6 +463,14 @@ __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__rest
         for (int r = 0; r < 4; ++r) wv[i - 1][r] = UOC_EXP(kappa * Sv[i - 1][r]);
       }
       if (i < ST) Sv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (NH > 1 && i < ST) {  // second half of the dot products (not interleaved: 'cat' is the rare mode)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int v = k >> 2, e = k & 3;
+          const float4 zb = *reinterpret_cast<const float4 *>(Zt + (ST * 16 + 16 * i + t) * ZP + 16 * v + 4 * q);
+          Sv[i] = mfma4(f4c(xa[4 + v], e), f4c(zb, e), Sv[i]);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         if (i < ST) {
@@ -454,10 +484,14 @@ __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__rest
         }
       }
     }
+    if (NH == 1) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      xa[v] = na[v];
-      xb[v] = nb[v];
+      for (int v = 0; v < 4; ++v) {
+        xa[v] = na[v];
+        xb[v] = nb[v];
+      }
+    } else {
+      load_tile(tile + stride, xa, xb);  // no double buffering: the registers go to the second half of the row
     }
   }
 
@@ -501,30 +535,42 @@ __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__rest
 }
 
 // Z[seed] = normalize(sum_blk partial[blk][seed])  (F.normalize, eps 1e-12; mean_shift.py:107)
+// partial [b][blk][NH][rows][64] -> Z [b][NH][m][64], the norm runs over all NH * 64 channels.
+template <int NH>
 __global__ __launch_bounds__(256) void hc_finalize_kernel(const float *__restrict__ partial, int nblk, int rows,
                                                           int m, float *__restrict__ Z) {
   const int b = blockIdx.y, seed = blockIdx.x;
   const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const float *src = partial + ((size_t)b * nblk * rows + seed) * C + c;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int blk = w;
-  for (; blk + 12 < nblk; blk += 16) {
-    s0 += src[(size_t)blk * rows * C];
-    s1 += src[(size_t)(blk + 4) * rows * C];
-    s2 += src[(size_t)(blk + 8) * rows * C];
-    s3 += src[(size_t)(blk + 12) * rows * C];
+  __shared__ float red[NH][4][C];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const float *src = partial + (((size_t)b * nblk * NH + h) * rows + seed) * C + c;
+    const size_t bs = (size_t)NH * rows * C;  // block stride
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int blk = w;
+    for (; blk + 12 < nblk; blk += 16) {
+      s0 += src[(size_t)blk * bs];
+      s1 += src[(size_t)(blk + 4) * bs];
+      s2 += src[(size_t)(blk + 8) * bs];
+      s3 += src[(size_t)(blk + 12) * bs];
+    }
+    for (; blk < nblk; blk += 4) s0 += src[(size_t)blk * bs];
+    red[h][w][c] = (s0 + s1) + (s2 + s3);
   }
-  for (; blk < nblk; blk += 4) s0 += src[(size_t)blk * rows * C];
-  __shared__ float red[4][C];
-  red[w][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (w == 0) {
-    const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
-    float ss = v * v;
+    float v[NH];
+    float ss = 0.f;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      v[h] = (red[h][0][c] + red[h][1][c]) + (red[h][2][c] + red[h][3][c]);
+      ss = h == 0 ? v[h] * v[h] : fmaf(v[h], v[h], ss);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
     const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-    Z[((size_t)b * m + seed) * C + c] = v / nrm;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) Z[(((size_t)b * NH + h) * m + seed) * C + c] = v[h] / nrm;
   }
 }
 
@@ -533,12 +579,17 @@ __global__ __launch_bounds__(256) void hc_finalize_kernel(const float *__restric
 // so ONE wavefront per batch item; lane l owns seeds l and l+64.  Quirks kept: the component
 // takes the MODE of already-present labels (ties -> smallest) and overwrites every member.
 // -------------------------------------------------------------------------------------------
+template <int NH>
 __global__ __launch_bounds__(64) void seed_cc_kernel(const float *__restrict__ Z, int m, float eps,
                                                      int *__restrict__ seed_labels, int *__restrict__ num_unique) {
-  __shared__ float Zs[NLAB * (C + 1)];
+  constexpr int CW = NH * C;  // a seed row in LDS: the NH halves back to back, pitch CW + 1
+  extern __shared__ __attribute__((aligned(16))) float Zs[];  // [NLAB][CW + 1]
   const int b = blockIdx.x, lane = threadIdx.x;
-  Z += (size_t)b * m * C;
-  for (int i = lane; i < m * C; i += 64) Zs[(i / C) * (C + 1) + (i % C)] = Z[i];
+  Z += (size_t)b * NH * m * C;
+  for (int i = lane; i < NH * m * C; i += 64) {
+    const int h = i / (m * C), j = i % (m * C);
+    Zs[(j / C) * (CW + 1) + h * C + (j % C)] = Z[i];
+  }
   __syncthreads();
   const bool have0 = lane < m, have1 = lane + 64 < m;
   int lab0 = -1, lab1 = -1, next = 0;
@@ -546,13 +597,13 @@ __global__ __launch_bounds__(64) void seed_cc_kernel(const float *__restrict__ Z
     const int li = (i < 64) ? __shfl(lab0, i) : __shfl(lab1, i - 64);
     if (li != -1) continue;
     float dot0 = 0.f, dot1 = 0.f;
-    const float *zi = Zs + i * (C + 1);
-    const float *z0 = Zs + lane * (C + 1);
-    const float *z1 = Zs + (lane + 64) * (C + 1);
+    const float *zi = Zs + i * (CW + 1);
+    const float *z0 = Zs + lane * (CW + 1);
+    const float *z1 = Zs + (lane + 64) * (CW + 1);
     if (have0)
-      for (int c = 0; c < C; ++c) dot0 = fmaf(z0[c], zi[c], dot0);
+      for (int c = 0; c < CW; ++c) dot0 = fmaf(z0[c], zi[c], dot0);
     if (have1)
-      for (int c = 0; c < C; ++c) dot1 = fmaf(z1[c], zi[c], dot1);
+      for (int c = 0; c < CW; ++c) dot1 = fmaf(z1[c], zi[c], dot1);
     const bool in0 = have0 && (0.5f * (1.0f - dot0) <= eps);
     const bool in1 = have1 && (0.5f * (1.0f - dot1) <= eps);
     unsigned long long lm0 = __ballot(in0 && lab0 != -1), lm1 = __ballot(in1 && lab1 != -1);
@@ -598,18 +649,18 @@ __global__ __launch_bounds__(64) void seed_cc_kernel(const float *__restrict__ Z
 // Nearest-seed assignment: S = X Z^T on fp32 MFMA, d = 0.5(1 - S), argmin over seeds
 // (ties -> lowest seed index, torch.argmin), label = seed_labels[argmin], per-label histogram.
 // -------------------------------------------------------------------------------------------
-template <int ST>
+template <int ST, int NH>
 __global__ __launch_bounds__(HC_THREADS) void assign_kernel(const float *__restrict__ X, int n,
                                                             const float *__restrict__ Z,
                                                             const int *__restrict__ seed_labels, int m,
                                                             int *__restrict__ labels, int *__restrict__ closest,
                                                             int *__restrict__ counts) {
-  __shared__ __attribute__((aligned(16))) float Zs[ST * 16 * ZP];
+  extern __shared__ __attribute__((aligned(16))) float Zs[];  // [NH][ST * 16][ZP]
   __shared__ int slab[NLAB];
   __shared__ int hist[NLAB];
   const int b = blockIdx.y;
-  X += (size_t)b * n * C;
-  Z += (size_t)b * m * C;
+  X += (size_t)b * NH * n * C;
+  Z += (size_t)b * NH * m * C;
   seed_labels += (size_t)b * m;
   labels += (size_t)b * n;
   if (closest) closest += (size_t)b * n;
@@ -617,11 +668,12 @@ __global__ __launch_bounds__(HC_THREADS) void assign_kernel(const float *__restr
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = lane & 15, q = lane >> 4;
-  for (int i = tid; i < ST * 16 * (C / 4); i += HC_THREADS) {
-    const int row = i / (C / 4), c4 = i % (C / 4);
+  for (int i = tid; i < NH * ST * 16 * (C / 4); i += HC_THREADS) {
+    const int h = i / (ST * 16 * (C / 4)), j = i % (ST * 16 * (C / 4));
+    const int row = j / (C / 4), c4 = j % (C / 4);
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < m) v = *reinterpret_cast<const float4 *>(Z + (size_t)row * C + 4 * c4);
-    *reinterpret_cast<float4 *>(Zs + row * ZP + 4 * c4) = v;
+    if (row < m) v = *reinterpret_cast<const float4 *>(Z + ((size_t)h * m + row) * C + 4 * c4);
+    *reinterpret_cast<float4 *>(Zs + (h * ST * 16 + row) * ZP + 4 * c4) = v;
   }
   if (tid < NLAB) {
     slab[tid] = tid < m ? seed_labels[tid] : 0;
@@ -632,10 +684,10 @@ __global__ __launch_bounds__(HC_THREADS) void assign_kernel(const float *__restr
   const int ntile = (n + 15) >> 4;
   for (int tile = blockIdx.x * (HC_THREADS / 64) + wave; tile < ntile; tile += gridDim.x * (HC_THREADS / 64)) {
     const int pa = tile * 16 + t;
-    float4 xa[4];
+    float4 xa[NH * 4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
-      xa[v] = (pa < n) ? *reinterpret_cast<const float4 *>(X + (size_t)pa * C + 16 * v + 4 * q)
+    for (int v = 0; v < NH * 4; ++v)
+      xa[v] = (pa < n) ? *reinterpret_cast<const float4 *>(X + ((size_t)(v >> 2) * n + pa) * C + 16 * (v & 3) + 4 * q)
                        : make_float4(0.f, 0.f, 0.f, 0.f);
     float bd[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
     int bi[4] = {INT_MAX, INT_MAX, INT_MAX, INT_MAX};
@@ -643,8 +695,9 @@ __global__ __launch_bounds__(HC_THREADS) void assign_kernel(const float *__restr
     for (int s = 0; s < ST; ++s) {
       f32x4 S = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const float4 zb = *reinterpret_cast<const float4 *>(Zs + (16 * s + t) * ZP + 16 * v + 4 * q);
+      for (int v = 0; v < NH * 4; ++v) {
+        const float4 zb =
+            *reinterpret_cast<const float4 *>(Zs + ((v >> 2) * ST * 16 + 16 * s + t) * ZP + 16 * (v & 3) + 4 * q);
         S = mfma4(xa[v].x, zb.x, S);
         S = mfma4(xa[v].y, zb.y, S);
         S = mfma4(xa[v].z, zb.z, S);
@@ -732,6 +785,7 @@ struct MsWorkspace {
   int *seed_labels;   // [batch][128]
   float *Z;           // [batch][128][64]
   int hc_nblk;
+  int nh;  // 64-channel halves per embedding (1, or 2 for 128-d fields)
   size_t total;
 };
 
@@ -754,7 +808,7 @@ static int hc_blocks(int batch, int n) {
   return nblk;
 }
 
-static MsWorkspace carve(void *base, int batch, int n) {
+static MsWorkspace carve(void *base, int batch, int n, int nh = 1) {
   MsWorkspace w;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -766,22 +820,23 @@ static MsWorkspace carve(void *base, int batch, int n) {
   w.dmin = (float *)take((size_t)batch * n * sizeof(float));
   w.part[0] = (ArgMax *)take((size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax));
   w.part[1] = (ArgMax *)take((size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax));
-  w.hc_partial = (float *)take((size_t)batch * w.hc_nblk * NLAB * C * sizeof(float));
+  w.hc_partial = (float *)take((size_t)batch * w.hc_nblk * nh * NLAB * C * sizeof(float));
   w.counts = (int *)take((size_t)batch * NLAB * sizeof(int));
   w.num_unique = (int *)take((size_t)batch * sizeof(int));
   w.seed_labels = (int *)take((size_t)batch * NLAB * sizeof(int));
-  w.Z = (float *)take((size_t)batch * NLAB * C * sizeof(float));
+  w.Z = (float *)take((size_t)batch * nh * NLAB * C * sizeof(float));
+  w.nh = nh;
   w.total = off;
   return w;
 }
 
-static int check_common(const void *X, int batch, int n, int m, void *ws, size_t ws_bytes) {
+static int check_common(const void *X, int batch, int n, int m, void *ws, size_t ws_bytes, int nh = 1) {
   UOC_REQUIRE(X != nullptr, "X is null");
   UOC_REQUIRE(batch >= 1 && batch <= 65535, "batch=%d out of range [1,65535]", batch);
   UOC_REQUIRE(n >= 1, "n=%d must be >= 1", n);
   UOC_REQUIRE(m >= 1 && m <= UOC_MAX_SEEDS, "num_seeds=%d out of range [1,%d]", m, UOC_MAX_SEEDS);
   UOC_REQUIRE(((uintptr_t)X & 15) == 0, "X must be 16-byte aligned");
-  const size_t need = carve(nullptr, batch, n).total;
+  const size_t need = carve(nullptr, batch, n, nh).total;
   UOC_REQUIRE(ws != nullptr && ws_bytes >= need, "workspace too small: %zu < %zu", ws_bytes, need);
   UOC_REQUIRE(((uintptr_t)ws & 255) == 0, "workspace must be 256-byte aligned");
   return UOC_OK;
@@ -830,7 +885,7 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
   // Persistent path: as many items per cooperative launch as stay co-resident; a larger batch
   // (stage 2 with > 8 ROIs) is split into several launches rather than dropped to the streaming kernel.
   int done = 0;
-  while (m >= 2 && done < batch) {
+  while (m >= 2 && done < batch && w.nh == 1) {  // the on-chip kernel holds 64-d rows; 128-d fields stream
     int sub = batch - done, bpi = 0, nslots = 0;
     while (sub > 1 && !fps_persistent_plan(sub, n, &bpi, &nslots)) sub = (sub + 1) / 2;
     if (!fps_persistent_plan(sub, n, &bpi, &nslots)) break;
@@ -866,8 +921,8 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
     done += sub;
   }
   if (done >= batch) return UOC_OK;
-  return run_select_seeds_streaming(X + (size_t)done * n * C, batch - done, n, m, first + done,
-                                    seeds + (size_t)done * m * C, indices + (size_t)done * m, w, st);
+  return run_select_seeds_streaming(X + (size_t)done * w.nh * n * C, batch - done, n, m, first + done,
+                                    seeds + (size_t)done * w.nh * m * C, indices + (size_t)done * m, w, st);
 }
 
 static int run_select_seeds_streaming(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
@@ -876,76 +931,133 @@ static int run_select_seeds_streaming(const float *X, int batch, int n, int m, c
   for (int s = 0; s < m; ++s) {
     dim3 grid(nblk, batch);  // gridDim.x doubles as the partial count, so it is the same every step
     const bool last = s == m - 1;
-    ProfScope prof(KC_FPS_STEP, st, last ? 0.0 : 2.0 * batch * n * C, last ? 0.0 : 4.0 * batch * ((double)n * C + 2.0 * n));
-    hipLaunchKernelGGL(fps_step_kernel, grid, dim3(FPS_THREADS), 0, st, X, n, m, s, first, w.dmin, seeds, indices,
-                       w.part[(s + 1) & 1], w.part[s & 1]);
+    ProfScope prof(KC_FPS_STEP, st, last ? 0.0 : 2.0 * batch * n * C * w.nh,
+                   last ? 0.0 : 4.0 * batch * ((double)n * C * w.nh + 2.0 * n));
+    if (w.nh == 2)
+      hipLaunchKernelGGL(fps_step_kernel<2>, grid, dim3(FPS_THREADS), 0, st, X, n, m, s, first, w.dmin, seeds, indices,
+                         w.part[(s + 1) & 1], w.part[s & 1]);
+    else
+      hipLaunchKernelGGL(fps_step_kernel<1>, grid, dim3(FPS_THREADS), 0, st, X, n, m, s, first, w.dmin, seeds, indices,
+                         w.part[(s + 1) & 1], w.part[s & 1]);
   }
   UOC_LAUNCH_CHECK();
   return UOC_OK;
 }
 
-template <int ST>
+template <int ST, int NH>
 static void launch_hc(const float *X, int batch, int n, float *Z, int m, float kappa, int iters,
                       const MsWorkspace &w, hipStream_t st) {
-  const size_t zbytes = (size_t)ST * 16 * ZP * sizeof(float);
+  const size_t zbytes = (size_t)NH * ST * 16 * ZP * sizeof(float);
   const size_t rbytes = (size_t)2 * ST * 4 * 64 * sizeof(f32x4);
   const size_t lds = zbytes > rbytes ? zbytes : rbytes;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hc_iter_kernel<ST, NH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
   for (int it = 0; it < iters; ++it) {
     {
-      ProfScope prof(KC_HC_ITER, st, 4.0 * batch * m * (double)n * C, 4.0 * batch * ((double)n * C + 2.0 * m * C));
-      hipLaunchKernelGGL(hc_iter_kernel<ST>, dim3(w.hc_nblk, batch), dim3(HC_THREADS), lds, st, X, n, Z, m, kappa,
-                         w.hc_partial);
+      // NH = 2 recomputes S for each half of the accumulators: (2 + 1) / 2 of the algorithmic flops per half
+      ProfScope prof(KC_HC_ITER, st, 4.0 * batch * m * (double)n * C * NH,
+                     4.0 * batch * ((double)n * C * NH + 2.0 * m * C * NH));
+      hipLaunchKernelGGL((hc_iter_kernel<ST, NH>), dim3(w.hc_nblk, batch, NH), dim3(HC_THREADS), lds, st, X, n, Z, m,
+                         kappa, w.hc_partial);
     }
-    ProfScope prof(KC_HC_FINALIZE, st, 0.0, 4.0 * batch * w.hc_nblk * ST * 16.0 * C);
-    hipLaunchKernelGGL(hc_finalize_kernel, dim3(m, batch), dim3(256), 0, st, w.hc_partial, w.hc_nblk, ST * 16, m, Z);
+    ProfScope prof(KC_HC_FINALIZE, st, 0.0, 4.0 * batch * w.hc_nblk * NH * ST * 16.0 * C);
+    hipLaunchKernelGGL(hc_finalize_kernel<NH>, dim3(m, batch), dim3(256), 0, st, w.hc_partial, w.hc_nblk, ST * 16, m, Z);
+  }
+}
+
+template <int NH>
+static void run_hill_climb_nh(const float *X, int batch, int n, float *Z, int m, float kappa, int iters,
+                              const MsWorkspace &w, hipStream_t st) {
+  switch ((m + 15) / 16) {
+    case 1: launch_hc<1, NH>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 2: launch_hc<2, NH>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 3: launch_hc<3, NH>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 4: launch_hc<4, NH>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 5: launch_hc<5, NH>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 6: launch_hc<6, NH>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    case 7: launch_hc<7, NH>(X, batch, n, Z, m, kappa, iters, w, st); break;
+    default: launch_hc<8, NH>(X, batch, n, Z, m, kappa, iters, w, st); break;
   }
 }
 
 static int run_hill_climb(const float *X, int batch, int n, float *Z, int m, float kappa, int iters,
                           const MsWorkspace &w, hipStream_t st) {
-  switch ((m + 15) / 16) {
-    case 1: launch_hc<1>(X, batch, n, Z, m, kappa, iters, w, st); break;
-    case 2: launch_hc<2>(X, batch, n, Z, m, kappa, iters, w, st); break;
-    case 3: launch_hc<3>(X, batch, n, Z, m, kappa, iters, w, st); break;
-    case 4: launch_hc<4>(X, batch, n, Z, m, kappa, iters, w, st); break;
-    case 5: launch_hc<5>(X, batch, n, Z, m, kappa, iters, w, st); break;
-    case 6: launch_hc<6>(X, batch, n, Z, m, kappa, iters, w, st); break;
-    case 7: launch_hc<7>(X, batch, n, Z, m, kappa, iters, w, st); break;
-    default: launch_hc<8>(X, batch, n, Z, m, kappa, iters, w, st); break;
-  }
+  if (w.nh == 2)
+    run_hill_climb_nh<2>(X, batch, n, Z, m, kappa, iters, w, st);
+  else
+    run_hill_climb_nh<1>(X, batch, n, Z, m, kappa, iters, w, st);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
 }
 
-template <int ST>
+template <int ST, int NH>
 static void launch_assign(const float *X, int batch, int n, const float *Z, const int *seed_labels, int m,
                           int *labels, int *closest, const MsWorkspace &w, hipStream_t st) {
   int nblk = hc_blocks(batch, n) * 2;
   const int maxb = ((n + 15) / 16 + 3) / 4;
   if (nblk > maxb) nblk = maxb;
-  ProfScope prof(KC_ASSIGN, st, 2.0 * batch * m * (double)n * C, 4.0 * batch * ((double)n * C + n));
-  hipLaunchKernelGGL(assign_kernel<ST>, dim3(nblk, batch), dim3(HC_THREADS), 0, st, X, n, Z, seed_labels, m, labels,
-                     closest, w.counts);
+  const size_t lds = (size_t)NH * ST * 16 * ZP * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&assign_kernel<ST, NH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  ProfScope prof(KC_ASSIGN, st, 2.0 * batch * m * (double)n * C * NH, 4.0 * batch * ((double)n * C * NH + n));
+  hipLaunchKernelGGL((assign_kernel<ST, NH>), dim3(nblk, batch), dim3(HC_THREADS), lds, st, X, n, Z, seed_labels, m,
+                     labels, closest, w.counts);
+}
+
+template <int NH>
+static void run_assign_nh(const float *X, int batch, int n, const float *Z, const int *seed_labels, int m, int *labels,
+                          int *closest, const MsWorkspace &w, hipStream_t st) {
+  switch ((m + 15) / 16) {
+    case 1: launch_assign<1, NH>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 2: launch_assign<2, NH>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 3: launch_assign<3, NH>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 4: launch_assign<4, NH>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 5: launch_assign<5, NH>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 6: launch_assign<6, NH>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    case 7: launch_assign<7, NH>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+    default: launch_assign<8, NH>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
+  }
 }
 
 static int run_assign(const float *X, int batch, int n, const float *Z, const int *seed_labels,
                       const int *num_unique, int m, int *labels, int *closest, const MsWorkspace &w,
                       hipStream_t st) {
   UOC_HIP_CHECK(hipMemsetAsync(w.counts, 0, (size_t)batch * NLAB * sizeof(int), st));
-  switch ((m + 15) / 16) {
-    case 1: launch_assign<1>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
-    case 2: launch_assign<2>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
-    case 3: launch_assign<3>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
-    case 4: launch_assign<4>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
-    case 5: launch_assign<5>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
-    case 6: launch_assign<6>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
-    case 7: launch_assign<7>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
-    default: launch_assign<8>(X, batch, n, Z, seed_labels, m, labels, closest, w, st); break;
-  }
+  if (w.nh == 2)
+    run_assign_nh<2>(X, batch, n, Z, seed_labels, m, labels, closest, w, st);
+  else
+    run_assign_nh<1>(X, batch, n, Z, seed_labels, m, labels, closest, w, st);
   int rb = (n + 255) / 256;
   if (rb > 512) rb = 512;
   ProfScope prof(KC_RELABEL, st, 0.0, 8.0 * batch * n);
   hipLaunchKernelGGL(relabel_swap_kernel, dim3(rb, batch), dim3(256), 0, st, labels, n, w.counts, num_unique);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+static int run_seed_cc(const float *Z, int batch, int m, float eps, int *seed_labels, int *num_unique, int nh,
+                       hipStream_t st) {
+  ProfScope prof(KC_SEED_CC, st, 0.0, 4.0 * batch * m * C * nh);
+  const size_t lds = (size_t)NLAB * (nh * C + 1) * sizeof(float);
+  if (nh == 2) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&seed_cc_kernel<2>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(seed_cc_kernel<2>, dim3(batch), dim3(64), lds, st, Z, m, eps, seed_labels, num_unique);
+  } else {
+    hipLaunchKernelGGL(seed_cc_kernel<1>, dim3(batch), dim3(64), lds, st, Z, m, eps, seed_labels, num_unique);
+  }
   UOC_LAUNCH_CHECK();
   return UOC_OK;
 }
@@ -987,10 +1099,7 @@ int uoc_ms_seed_components(const float *d_Z, int batch, int m, float epsilon, in
                            int32_t *d_num_unique, void *stream) {
   UOC_REQUIRE(d_Z && d_seed_labels && d_num_unique, "null pointer");
   UOC_REQUIRE(batch >= 1 && m >= 1 && m <= UOC_MAX_SEEDS, "batch=%d m=%d out of range", batch, m);
-  hipLaunchKernelGGL(seed_cc_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, d_Z, m, epsilon, d_seed_labels,
-                     d_num_unique);
-  UOC_LAUNCH_CHECK();
-  return UOC_OK;
+  return run_seed_cc(d_Z, batch, m, epsilon, d_seed_labels, d_num_unique, 1, (hipStream_t)stream);
 }
 
 int uoc_ms_assign(const float *d_X, int batch, int n, const float *d_Z, const int32_t *d_seed_labels,
@@ -1014,11 +1123,30 @@ int uoc_ms_cluster(const float *d_X, int batch, int n, int m, float kappa, int i
   int *sl = d_seed_labels_out ? d_seed_labels_out : w.seed_labels;
   if (int rc = run_select_seeds(d_X, batch, n, m, d_first_index, Z, d_indices, w, st)) return rc;
   if (int rc = run_hill_climb(d_X, batch, n, Z, m, kappa, iters, w, st)) return rc;
-  {
-    ProfScope prof(KC_SEED_CC, st, 0.0, 4.0 * batch * m * C);
-    hipLaunchKernelGGL(seed_cc_kernel, dim3(batch), dim3(64), 0, st, Z, m, epsilon, sl, w.num_unique);
-  }
-  UOC_LAUNCH_CHECK();
+  if (int rc = run_seed_cc(Z, batch, m, epsilon, sl, w.num_unique, 1, st)) return rc;
+  return run_assign(d_X, batch, n, Z, sl, w.num_unique, m, d_labels, nullptr, w, st);
+}
+
+size_t uoc_ms_workspace_bytes_wide(int batch, int n, int m, int halves) {
+  (void)m;
+  if (batch < 1 || n < 1 || halves < 1 || halves > 2) return 0;
+  return carve(nullptr, batch, n, halves).total;
+}
+
+int uoc_ms_cluster_wide(const float *d_X, int halves, int batch, int n, int m, float kappa, int iters, float epsilon,
+                        const int32_t *d_first_index, int32_t *d_labels, int32_t *d_indices, float *d_Z_out,
+                        int32_t *d_seed_labels_out, void *d_ws, size_t ws_bytes, void *stream) {
+  UOC_REQUIRE(halves == 1 || halves == 2, "halves=%d (64-d or 128-d embeddings only)", halves);
+  if (int rc = check_common(d_X, batch, n, m, d_ws, ws_bytes, halves)) return rc;
+  UOC_REQUIRE(d_first_index && d_labels && d_indices, "null pointer");
+  UOC_REQUIRE(iters >= 0, "iters=%d must be >= 0", iters);
+  hipStream_t st = (hipStream_t)stream;
+  MsWorkspace w = carve(d_ws, batch, n, halves);
+  float *Z = d_Z_out ? d_Z_out : w.Z;
+  int *sl = d_seed_labels_out ? d_seed_labels_out : w.seed_labels;
+  if (int rc = run_select_seeds(d_X, batch, n, m, d_first_index, Z, d_indices, w, st)) return rc;
+  if (int rc = run_hill_climb(d_X, batch, n, Z, m, kappa, iters, w, st)) return rc;
+  if (int rc = run_seed_cc(Z, batch, m, epsilon, sl, w.num_unique, halves, st)) return rc;
   return run_assign(d_X, batch, n, Z, sl, w.num_unique, m, d_labels, nullptr, w, st);
 }
 

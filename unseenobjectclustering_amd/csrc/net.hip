@@ -42,7 +42,7 @@ struct uoc_net {
   int device = -1;
   int wino_min_cin = 256;  // 3x3 stride-1 layers with Cin >= this run as Winograd F(2x2,3x3); 0 = never
   int mode = UOC_NET_RGBD_ADD;
-  int G = 2;  // backbones evaluated side by side (2 only for RGBD 'add')
+  int G = 2;  // backbones evaluated side by side (2 for RGBD 'add' and 'cat')
 };
 
 namespace uoc {
@@ -198,8 +198,8 @@ struct NetWs {
 };
 static NetWs carve_net(void *base, int mode, int B, int H, int W) {
   const Dims d = dims(H, W);
-  const int G = mode == UOC_NET_RGBD_ADD ? 2 : 1;
-  const int n_in = (mode == UOC_NET_RGBD_ADD || mode == UOC_NET_RGBD_EARLY) ? 2 : 1;
+  const int G = (mode == UOC_NET_RGBD_ADD || mode == UOC_NET_RGBD_CAT) ? 2 : 1;
+  const int n_in = (G == 2 || mode == UOC_NET_RGBD_EARLY) ? 2 : 1;
   NetWs w;
   size_t off = 0;
   auto take = [&](size_t floats) {
@@ -264,19 +264,21 @@ int uoc_net_create(uoc_net **out) { return uoc_net_create_mode(out, UOC_NET_RGBD
 
 int uoc_net_create_mode(uoc_net **out, int mode) {
   UOC_REQUIRE(out != nullptr, "out is null");
-  UOC_REQUIRE(mode >= UOC_NET_RGBD_ADD && mode <= UOC_NET_RGBD_EARLY, "unknown network mode %d", mode);
+  UOC_REQUIRE(mode >= UOC_NET_RGBD_ADD && mode <= UOC_NET_RGBD_CAT, "unknown network mode %d", mode);
   uoc_net *n = new (std::nothrow) uoc_net();
   if (!n) {
     set_error("out of host memory");
     return UOC_ENOMEM;
   }
   n->mode = mode;
-  n->G = mode == UOC_NET_RGBD_ADD ? 2 : 1;
+  n->G = (mode == UOC_NET_RGBD_ADD || mode == UOC_NET_RGBD_CAT) ? 2 : 1;
   build_graph(n);
   if (const char *e = getenv("UOC_WINOGRAD_MIN_CIN")) n->wino_min_cin = atoi(e);  // 0 disables the Winograd path
   *out = n;
   return UOC_OK;
 }
+
+int uoc_net_embed_dim(const uoc_net *n) { return n && n->mode == UOC_NET_RGBD_CAT ? 128 : 64; }
 
 int uoc_net_destroy(uoc_net *n) {
   if (!n) return UOC_OK;
@@ -365,7 +367,8 @@ int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, i
     wd = wo;
   }
   if (int rc = run_conv(G, n->layers[n->fc], w.buf[cur], nullptr, w.fc, B, h, wd, h, wd, st)) return rc;
-  return launch_head(w.fc, G == 2 ? w.fc + (size_t)B * h * wd * 64 : nullptr, d_embed, B, h, wd, H, W, st);
+  return launch_head(w.fc, G == 2 ? w.fc + (size_t)B * h * wd * 64 : nullptr, d_embed, B, h, wd, H, W,
+                     n->mode == UOC_NET_RGBD_CAT, st);
 }
 
 /* Generic NHWC convolution entry (unit tests / integration): G independent groups stacked on the

@@ -1,8 +1,8 @@
 """Process-global config object `cfg` — the subset of the reference's lib/fcn/config.py that the
 inference hot path reads, with the values the RGB-D `add` / cosine experiment
 config sets (experiments/cfgs/seg_resnet34_8s_embedding_cosine_rgbd_add_tabletop.yml).  cfg.INPUT
-'COLOR' / 'DEPTH' and FUSION_TYPE 'early' (the other shipped experiment configs) are implemented too;
-'cat' is not.
+'COLOR' / 'DEPTH' and FUSION_TYPE 'early' / 'cat' (the other shipped experiment configs) are
+implemented too.
 
 The reference's default EMBEDDING_METRIC is 'euclidean' (config.py:261) and every shipped
 experiment overrides it to 'cosine'; this build implements the cosine path only and raises if
@@ -46,7 +46,8 @@ cfg.TEST.VISUALIZE = False             # config.py:319
 
 
 def network_mode() -> str:
-    """'RGBD_ADD' | 'COLOR' | 'DEPTH' | 'RGBD_EARLY' from cfg.INPUT / cfg.TRAIN.FUSION_TYPE (SEG.py:69-71,97-110)."""
+    """'RGBD_ADD' | 'COLOR' | 'DEPTH' | 'RGBD_EARLY' | 'RGBD_CAT' from cfg.INPUT / cfg.TRAIN.FUSION_TYPE
+    (SEG.py:69-71,97-110)."""
     if cfg.INPUT == "COLOR":
         return "COLOR"
     if cfg.INPUT == "DEPTH":
@@ -56,8 +57,7 @@ def network_mode() -> str:
             return "RGBD_ADD"
         if cfg.TRAIN.FUSION_TYPE == "early":
             return "RGBD_EARLY"
-        raise NotImplementedError("cfg.TRAIN.FUSION_TYPE=%r: only 'add' and 'early' are implemented on gfx950 "
-                                  "('cat' needs 128-d clustering kernels)" % (cfg.TRAIN.FUSION_TYPE,))
+        return "RGBD_CAT"       # SEG.py:107-110: anything that is neither 'add' nor 'early' concatenates
     raise NotImplementedError("cfg.INPUT=%r is not one of 'RGBD', 'COLOR', 'DEPTH'" % (cfg.INPUT,))
 
 

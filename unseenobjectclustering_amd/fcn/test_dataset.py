@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from .. import _native
-from ..utils.mean_shift import cluster_batch
+from ..utils.mean_shift import cluster_batch, to_planes
 from .config import cfg, require_supported, uses_depth
 
 KAPPA = 20            # test_dataset.py:51
@@ -59,8 +59,14 @@ def _cluster_device(features: torch.Tensor, num_seeds: int = 100):
     require_supported()
     if not features.is_cuda:
         raise _native.NativeError("features must be on a ROCm device (no CPU fallback)")
-    X = _pixel_major(features.float())
-    B, n, _ = X.shape
+    planes = getattr(features, "_uoc_planes", None)     # 128-d output of SEGNET ('cat' fusion): already in kernel layout
+    if planes is not None and planes.shape[0] == features.shape[0]:
+        X = planes
+    else:
+        X = _pixel_major(features.float())
+        if X.shape[-1] == 128:
+            X = to_planes(X)
+    B, n = X.shape[0], X.shape[-2]
     firsts = [np.random.randint(0, n) for _ in range(B)]   # mean_shift.py:155, one draw per field, in order
     return cluster_batch(X, firsts, KAPPA, num_seeds, MAX_ITERS, 2 * cfg.TRAIN.EMBEDDING_ALPHA)
 

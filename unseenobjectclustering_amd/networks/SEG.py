@@ -1,4 +1,4 @@
-"""SEGNET for network 'Resnet34_8s' — cfg.INPUT='RGBD' with FUSION_TYPE 'add' (two backbones) or
+"""SEGNET for network 'Resnet34_8s' — cfg.INPUT='RGBD' with FUSION_TYPE 'add' / 'cat' (two backbones) or
 'early' (one 6-channel backbone), 'COLOR', 'DEPTH' — host-side mirror of
 /root/reference/lib/networks/SEG.py:26-181.
 
@@ -22,7 +22,7 @@ from ..fcn.config import cfg, network_mode, require_supported
 from ..synth import resnet34_8s_param_shapes
 
 BRANCHES = ("fcn", "fcn_depth")
-_MODE_ID = {"RGBD_ADD": 0, "COLOR": 1, "DEPTH": 2, "RGBD_EARLY": 3}     # include/uoc_hip.h UOC_NET_*
+_MODE_ID = {"RGBD_ADD": 0, "COLOR": 1, "DEPTH": 2, "RGBD_EARLY": 3, "RGBD_CAT": 4}     # include/uoc_hip.h UOC_NET_*
 
 
 class _Node(nn.Module):
@@ -64,7 +64,7 @@ class SEGNET(nn.Module):
         self.input_type = cfg.INPUT
         self.fusion_type = cfg.TRAIN.FUSION_TYPE
         # SEG.py:69-71: fcn always; fcn_depth only for RGBD without early fusion
-        self.branches = BRANCHES if self.mode == "RGBD_ADD" else BRANCHES[:1]
+        self.branches = BRANCHES if self.mode in ("RGBD_ADD", "RGBD_CAT") else BRANCHES[:1]
         for br in self.branches:
             for name, shape in resnet34_8s_param_shapes(num_units, in_channels):
                 if name.endswith("num_batches_tracked"):
@@ -140,13 +140,20 @@ class SEGNET(nn.Module):
             "expects [B,3,H,W] image and XYZ tensors"
         self._ensure_native(dev)
         L = _native.lib()
-        embed = torch.empty((B, H * W, 64), dtype=torch.float32, device=dev)
+        cat = self.mode == "RGBD_CAT"
+        embed = torch.empty((B, 2, H * W, 64) if cat else (B, H * W, 64), dtype=torch.float32, device=dev)
         nbytes = L.uoc_net_workspace_bytes(self._handle, B, H, W)
         ws = _net_workspace(dev, nbytes)
         with torch.cuda.device(dev):
             rc = L.uoc_net_forward(self._handle, _native.ptr(img), _native.ptr(depth), B, H, W, _native.ptr(embed),
                                    _native.ptr(ws), ws.numel(), _native.stream_ptr(dev))
         _native.check(rc, "uoc_net_forward")
+        if cat:
+            # [B,128,H,W] like SEG.py:110 (a copy: the kernels keep 128-d fields as two 64-channel planes);
+            # the plane tensor rides along so that clustering_features consumes it without converting back
+            out = embed.view(B, 2, H, W, 64).permute(0, 1, 4, 2, 3).reshape(B, 128, H, W)
+            out._uoc_planes = embed
+            return out
         return embed.view(B, H, W, 64).permute(0, 3, 1, 2)
 
     def weight_parameters(self):

@@ -18,7 +18,7 @@ import torch
 from .. import _native
 from ..fcn.config import cfg
 
-EMBED_DIM = 64
+EMBED_DIM = 64          # one 64-channel "half"; 128-d ('cat' fusion) fields are two of them
 _ws_cache = {}
 
 
@@ -46,15 +46,24 @@ def _require_cosine(metric):
         raise NotImplementedError("only metric='cosine' is implemented on gfx950")
 
 
+def to_planes(X: torch.Tensor) -> torch.Tensor:
+    """[B, n, 128] pixel-major rows -> the [B, 2, n, 64] plane layout of the 128-d kernels (a copy)."""
+    B, n, d = X.shape
+    return X.view(B, n, d // EMBED_DIM, EMBED_DIM).permute(0, 2, 1, 3).contiguous()
+
+
 def cluster_batch(X: torch.Tensor, first_index, kappa: float = 20.0, num_seeds: int = 100, max_iters: int = 10,
                   epsilon: float = None, return_parts: bool = False):
     """Cluster B independent fields in one set of launches.
 
-    X [B, n, 64] float32 unit rows (pixel-major), first_index: B ints.
+    X [B, n, 64] float32 unit rows (pixel-major) — or, for 128-d embeddings, the plane layout
+    [B, 2, n, 64] (to_planes) — first_index: B ints.
     Returns labels [B, n] int32 and indices [B, num_seeds] int32 (device tensors); with
-    return_parts also the converged seeds Z [B, m, 64] and their labels [B, m].
+    return_parts also the converged seeds Z [B, m, 64] ([B, 2, m, 64]) and their labels [B, m].
     """
     X = _check_points(X)
+    if X.dim() == 4:
+        return _cluster_batch_wide(X, first_index, kappa, num_seeds, max_iters, epsilon, return_parts)
     assert X.dim() == 3
     B, n, _ = X.shape
     if epsilon is None:
@@ -78,12 +87,41 @@ def cluster_batch(X: torch.Tensor, first_index, kappa: float = 20.0, num_seeds: 
     return labels, indices
 
 
+def _cluster_batch_wide(X, first_index, kappa, num_seeds, max_iters, epsilon, return_parts):
+    B, H2, n, _ = X.shape
+    if H2 != 2:
+        raise NotImplementedError("embedding dimension must be 64 or 128 (two 64-channel planes)")
+    if epsilon is None:
+        epsilon = 2 * cfg.TRAIN.EMBEDDING_ALPHA
+    dev = X.device
+    L = _native.lib()
+    first = torch.as_tensor(np.asarray(first_index, dtype=np.int32).reshape(B)).to(dev)
+    labels = torch.empty((B, n), dtype=torch.int32, device=dev)
+    indices = torch.empty((B, num_seeds), dtype=torch.int32, device=dev)
+    Z = torch.empty((B, H2, num_seeds, EMBED_DIM), dtype=torch.float32, device=dev)
+    seed_labels = torch.empty((B, num_seeds), dtype=torch.int32, device=dev)
+    ws = _workspace(dev, L.uoc_ms_workspace_bytes_wide(B, n, num_seeds, H2))
+    with torch.cuda.device(dev):
+        rc = L.uoc_ms_cluster_wide(_native.ptr(X), H2, B, n, num_seeds, float(kappa), int(max_iters), float(epsilon),
+                                   _native.ptr(first), _native.ptr(labels), _native.ptr(indices), _native.ptr(Z),
+                                   _native.ptr(seed_labels), _native.ptr(ws), ws.numel(), _native.stream_ptr(dev))
+    _native.check(rc, "uoc_ms_cluster_wide")
+    if return_parts:
+        return labels, indices, Z, seed_labels
+    return labels, indices
+
+
 def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine"):
-    """mean_shift.py:192-229.  X [n, d] unit rows on the GPU -> (labels [n] int64, indices [m] int64)."""
+    """mean_shift.py:192-229.  X [n, d] unit rows on the GPU, d = 64 or 128 -> (labels [n] int64, indices [m] int64)."""
     _require_cosine(metric)
     n = X.shape[0]
     first = np.random.randint(0, n)          # mean_shift.py:155 — same global-RNG draw as the reference
-    labels, indices = cluster_batch(X.unsqueeze(0), [first], kappa, num_seeds, max_iters)
+    Xb = X.unsqueeze(0)
+    if X.shape[-1] == 2 * EMBED_DIM:
+        if not X.is_cuda:
+            raise _native.NativeError("X must be on a ROCm device (no CPU fallback)")
+        Xb = to_planes(Xb.float())
+    labels, indices = cluster_batch(Xb, [first], kappa, num_seeds, max_iters)
     return labels[0].long(), indices[0].long().cpu()
 
 
