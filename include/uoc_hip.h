@@ -174,6 +174,27 @@ int uoc_roi_paste(const int32_t *d_labels_crop, const uoc_roi_table *d_table, co
 
 
 /* ------------------------------------------------------------------------------------------
+ * Evaluation — the integer statistics of multilabel_metrics (lib/utils/evaluation.py:109-257; overlap and
+ * boundary precision / recall of a predicted against a ground-truth label map).  The host mirror
+ * unseenobjectclustering_amd/utils/evaluation.py turns them into the reference's metric dictionary.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct uoc_eval_tables {
+  int32_t cont[128 * 128];     /* [gt][pred] pixels with that label pair (:188-190)                          */
+  int32_t prec_tp[128 * 128];  /* [gt][pred] boundary pixels of pred inside the dilated boundary of gt (:103)  */
+  int32_t rec_tp[128 * 128];   /* [gt][pred] boundary pixels of gt inside the dilated boundary of pred (:104)  */
+  int32_t bnd_pred[128];       /* boundary pixels (seg2bmap, :15-73) of every predicted mask (:212-215)        */
+  int32_t bnd_gt[128];         /* ... of every ground-truth mask (:216-219)                                    */
+  int32_t bad_label;           /* != 0: a label id outside [0, 128) was seen (such pixels are skipped)         */
+} uoc_eval_tables;
+
+size_t uoc_eval_workspace_bytes(int H, int W);
+/* d_pred, d_gt: [H][W] int32 label maps (0 = background); radius = bound_pix of boundary_overlap (:88-89),
+ * the dilation structuring element is the disk x^2 + y^2 <= radius^2 (:94-98). */
+int uoc_eval_pair_stats(const int32_t *d_pred, const int32_t *d_gt, int H, int W, int radius, uoc_eval_tables *d_tables,
+                        void *d_ws, size_t ws_bytes, void *stream);
+
+
+/* ------------------------------------------------------------------------------------------
  * Opt-in per-kernel timing (HIP events on the launch stream).  Single-threaded use.
  * uoc_prof_report writes a JSON array [{kernel, launches, total_ms, flops, bytes}, ...] where
  * flops/bytes are the ALGORITHMIC totals of the recorded launches.

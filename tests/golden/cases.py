@@ -110,3 +110,62 @@ MODE_BACKBONE_CASES = {
 }
 MODE_GLUE_CASES = ["normal_5", "border_8", "small_ragged"]       # GLUE_CASES re-run without depth (COLOR input)
 MODE_E2E_CASES = {"color_a": dict(seed=43, objects=4)}
+
+
+# ---------------------------------------------------------------------------------------------
+# Evaluation: multilabel_metrics on synthetic (prediction, ground truth) pairs.
+# ---------------------------------------------------------------------------------------------
+EVAL_CASES = {
+    # name -> (frame seed, H, W, objects, perturbation of the prediction)
+    "shifted":     dict(seed=51, H=240, W=320, objects=4, mode="shift"),
+    "merged":      dict(seed=52, H=240, W=320, objects=5, mode="merge"),
+    "split_extra": dict(seed=53, H=480, W=640, objects=3, mode="split"),
+    "permuted":    dict(seed=54, H=123, W=157, objects=6, mode="permute"),
+    "no_pred":     dict(seed=55, H=120, W=160, objects=3, mode="empty_pred"),
+    "no_gt":       dict(seed=56, H=120, W=160, objects=3, mode="empty_gt"),
+    "nothing":     dict(seed=57, H=120, W=160, objects=0, mode="empty_both"),
+}
+
+
+def eval_pair(c):
+    """(prediction, gt) int64 [H,W] maps: gt = generated scene (0 background, 1 table, 2.. objects), prediction = a
+    perturbed copy."""
+    gt = synth.rgbd_frame(c["seed"], c["H"], c["W"], c["objects"])["label"].astype(np.int64)
+    pred = gt.copy()
+    mode = c["mode"]
+    if mode == "shift":
+        pred = np.roll(np.roll(gt, 3, axis=0), -2, axis=1)
+    elif mode == "merge":
+        pred[pred == pred.max()] = pred.max() - 1
+        pred = np.roll(pred, 1, axis=1)
+    elif mode == "split":
+        top = pred.max()
+        ys = np.nonzero((pred == top).any(axis=1))[0]
+        pred[(pred == top) & (np.arange(pred.shape[0])[:, None] > ys.mean())] = top + 1
+        pred[5:25, 5:45] = top + 2                                   # a false-positive object
+    elif mode == "permute":
+        perm = np.arange(pred.max() + 1)
+        perm[1:] = np.roll(perm[1:], 2)
+        pred = perm[pred]
+        pred = np.roll(pred, 2, axis=0)
+    elif mode == "empty_pred":
+        pred[:] = 0
+    elif mode == "empty_gt":
+        gt = np.zeros_like(gt)
+    elif mode == "empty_both":
+        gt = np.zeros_like(gt)
+        pred = np.zeros_like(gt)
+    return pred, gt
+
+
+def munkres_cases():
+    """Cost matrices for the Hungarian matcher: square / rectangular, integer ties, floats, the F.max() - F form."""
+    rng = np.random.default_rng(20240611)
+    out = {"1x1": np.array([[3.0]]), "ties_4x4": rng.integers(0, 3, size=(4, 4)).astype(np.float64),
+           "ties_6x6": rng.integers(0, 4, size=(6, 6)).astype(np.float64), "tall_5x3": rng.random((5, 3)),
+           "wide_3x6": rng.random((3, 6)), "float_8x8": rng.random((8, 8)), "zeros_3x3": np.zeros((3, 3))}
+    F = rng.random((7, 5)) * (rng.random((7, 5)) > 0.5)
+    out["fmeasure_7x5"] = F.max() - F
+    F = rng.random((4, 9)) * (rng.random((4, 9)) > 0.6)
+    out["fmeasure_4x9"] = F.max() - F
+    return out

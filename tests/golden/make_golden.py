@@ -4,7 +4,7 @@ Imports the reference's own Python (through tests/golden/ref_harness.py) and rec
 outputs on repo-owned synthetic inputs.  The .npz files written next to this script are the
 fixtures tests/ compares the oracle (CPU) and the HIP path (GPU) against.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [meanshift|glue|backbone|e2e|demo|modes|all]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [meanshift|glue|backbone|e2e|demo|modes|evaluation|all]
 """
 from __future__ import annotations
 
@@ -22,6 +22,7 @@ sys.path.insert(0, HERE)
 import ref_harness  # noqa: E402
 from cases import (MEANSHIFT_CASES, KAPPA, EPSILON, RNG_SEED, BACKBONE_CASES, GLUE_CASES, E2E_CASES,  # noqa: E402
                    MODES, MODE_BACKBONE_CASES, MODE_GLUE_CASES, MODE_E2E_CASES, WIDE_MEANSHIFT_CASES,
+                   EVAL_CASES, eval_pair, munkres_cases,
                    sample_positions, glue_inputs, crop_cluster_labels, e2e_stub_features)
 from unseenobjectclustering_amd import synth  # noqa: E402
 
@@ -237,6 +238,41 @@ def make_modes(ref):
     np.savez_compressed(os.path.join(HERE, "modes.npz"), **out)
 
 
+def make_evaluation(ref):
+    """Reference metrics: munkres.py as is; evaluation.py with (a) np.bool aliased (removed from numpy 1.24) and
+    (b) boundary_overlap — which needs cv2.dilate + skimage.disk, absent here — replaced by a stub returning
+    (0, 0), so only the overlap metrics / counts of multilabel_metrics are recorded from it.  seg2bmap is recorded
+    separately (it is plain numpy)."""
+    import importlib
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    ev = importlib.import_module("utils.evaluation")
+    mk = importlib.import_module("utils.munkres")
+    out = {}
+    for name, cost in munkres_cases().items():
+        res = mk.Munkres().compute(cost.copy())
+        out[f"munkres/{name}/cost"] = cost
+        out[f"munkres/{name}/assign"] = np.asarray(res, dtype=np.int32).reshape(-1, 2)
+        print("munkres", name, res, flush=True)
+    real = ev.boundary_overlap
+    ev.boundary_overlap = lambda p, g, bound_th=0.003: (0, 0)
+    try:
+        keys = ["Objects F-measure", "Objects Precision", "Objects Recall", "obj_detected", "obj_detected_075", "obj_gt",
+                "obj_detected_075_percentage"]
+        for name, c in EVAL_CASES.items():
+            pred, gt = eval_pair(c)
+            m = ev.multilabel_metrics(pred.copy(), gt.copy())
+            out[f"metrics/{name}"] = np.array([float(m[k]) for k in keys], dtype=np.float64)
+            labs = [l for l in np.unique(pred) if l != 0][:3]
+            for l in labs:
+                out[f"bmap/{name}/{int(l)}"] = np.packbits(ev.seg2bmap(pred == l).astype(np.uint8), axis=None)
+            print("metrics", name, {k: round(float(m[k]), 4) for k in keys}, flush=True)
+        out["metrics/keys"] = np.array(keys)
+    finally:
+        ev.boundary_overlap = real
+    np.savez_compressed(os.path.join(HERE, "evaluation.npz"), **out)
+
+
 def main():
     assert ref_harness.available(), "reference tree not present: golden vectors can only be made in the build container"
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -254,6 +290,8 @@ def main():
         make_demo(ref)
     if what in ("modes", "all"):
         make_modes(ref)
+    if what in ("evaluation", "all"):
+        make_evaluation(ref)
 
 
 if __name__ == "__main__":

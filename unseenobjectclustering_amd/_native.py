@@ -46,6 +46,10 @@ def _declare(lib):
     for name in ("uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_forward",
                  "uoc_conv2d_nhwc"):
         getattr(lib, name).restype = c_int
+    lib.uoc_eval_workspace_bytes.restype = c_size_t
+    lib.uoc_eval_workspace_bytes.argtypes = [c_int, c_int]
+    lib.uoc_eval_pair_stats.argtypes = [P, P, c_int, c_int, c_int, P, P, c_size_t, P]
+    lib.uoc_eval_pair_stats.restype = c_int
     lib.uoc_roi_workspace_bytes.restype = c_size_t
     lib.uoc_roi_workspace_bytes.argtypes = []
     lib.uoc_prep_rgbd.argtypes = [P, P, c_int, c_int] + [c_float] * 7 + [P, P, P]
@@ -75,7 +79,7 @@ EXPORTED_SYMBOLS = (
     "uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",
     "uoc_net_forward", "uoc_conv2d_nhwc",
     "uoc_roi_workspace_bytes", "uoc_prep_rgbd", "uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats",
-    "uoc_roi_paste", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
+    "uoc_roi_paste", "uoc_eval_workspace_bytes", "uoc_eval_pair_stats", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
 )
 
 

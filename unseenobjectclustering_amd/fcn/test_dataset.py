@@ -274,27 +274,69 @@ def _run_frame(sample, network, network_crop, depth_threshold, return_device=Fal
     return out_label, out_label_refined
 
 
+def _print_average(metrics_all):
+    """test_dataset.py:346-357 — sum per key over the frames, divide by the frame count, print sorted."""
+    result = {}
+    num = len(metrics_all)
+    for metrics in metrics_all:
+        for k in metrics.keys():
+            result[k] = result.get(k, 0) + metrics[k]
+    for k in sorted(result.keys()):
+        result[k] /= num
+        print("%s: %f" % (k, result[k]))
+    return result
+
+
 def test_segnet(test_loader, network, output_dir, network_crop):
-    """test_dataset.py:271-381: dataset loop around the same per-frame body; writes one .mat per
-    sample (labels, labels_refined, filename) like the reference (:337-340).  The P/R/F metric
-    printout (:308-329,346-381) needs the datasets/evaluation stack that is outside this path."""
+    """test_dataset.py:271-381: dataset loop around the same per-frame body; per-frame segmentation metrics of
+    the stage-1 and the refined label maps against sample['label'] (multilabel_metrics, :308-329), one .mat
+    per sample (labels, labels_refined, filename; :337-340) and the averaged report (:346-381).  Samples
+    without a 'label' entry are segmented and saved but not scored."""
     import scipy.io
+    from ..utils.evaluation import multilabel_metrics
     network.eval()
     if network_crop is not None:
         network_crop.eval()
     epoch_size = len(test_loader)
     results = []
+    metrics_all, metrics_all_refined = [], []
     name = str(getattr(getattr(test_loader, "dataset", None), "name", ""))
     threshold = 0.5 if "ocid" in name else (0.8 if "osd" in name else None)      # :299-305
     for i, sample in enumerate(test_loader):
         end = time.time()
-        out_label, out_label_refined = _run_frame(sample, network, network_crop, threshold)
-        prediction = out_label.squeeze().numpy()
-        prediction_refined = out_label_refined.squeeze().numpy() if out_label_refined is not None else prediction.copy()
+        labels_dev, refined_dev = _run_frame(sample, network, network_crop, threshold, return_device=True)
+        prediction_dev = labels_dev.reshape(labels_dev.shape[-2:]) if labels_dev.shape[0] == 1 else labels_dev[0]
+        refined_2d = refined_dev[0] if refined_dev is not None else prediction_dev
+        prediction = labels_dev.float().cpu().squeeze().numpy()
+        prediction_refined = refined_dev.float().cpu().squeeze().numpy() if refined_dev is not None else prediction.copy()
         result = {"labels": prediction, "labels_refined": prediction_refined, "filename": sample.get("filename", "")}
+        if "label" in sample:
+            gt = sample["label"].squeeze()
+            metrics = multilabel_metrics(prediction_dev, gt)                     # :308-312
+            metrics_all.append(metrics)
+            print(metrics)
+            metrics_refined = multilabel_metrics(refined_2d, gt)                 # :324-329
+            metrics_all_refined.append(metrics_refined)
+            print(metrics_refined)
+            result["metrics"], result["metrics_refined"] = metrics, metrics_refined
         if output_dir is not None:
             filename = os.path.join(output_dir, "%06d.mat" % i)
-            scipy.io.savemat(filename, result, do_compression=True)
+            print(filename)
+            scipy.io.savemat(filename, {k: result[k] for k in ("labels", "labels_refined", "filename")},
+                             do_compression=True)
         results.append(result)
         print("[%d/%d], batch time %.2f" % (i, epoch_size, time.time() - end))
+    if metrics_all:
+        print("========================================================")
+        print("%d images" % len(metrics_all))
+        print("========================================================")
+        result = _print_average(metrics_all)
+        for k in ("Objects Precision", "Objects Recall", "Objects F-measure", "Boundary Precision", "Boundary Recall",
+                  "Boundary F-measure", "obj_detected_075_percentage"):
+            print("%.6f" % (result[k]))
+        print("========================================================")
+        print(result)
+        print("====================Refined=============================")
+        print(_print_average(metrics_all_refined))
+        print("========================================================")
     return results
