@@ -177,7 +177,11 @@ __device__ __forceinline__ f32x4 wmfma(float a, float b, f32x4 c) {
 // (= 70 % matrix-pipe busy in the full kernel, SQ_VALU_MFMA_BUSY_CYCLES).  What did NOT move the 37 us the
 // L2-sourced DMA costs: a 4-deep ring (NSTG = 4; so it is not latency), two dedicated producer waves issuing
 // all DMA (so it is not MFMA waves stalling on DMA issue), chunk-major U / V (-2 %), fewer L2 misses through
-// the XCD mapping (0 %).
+// the XCD mapping (0 %), and loading each wave's own U fragments straight into registers instead of through
+// LDS (-44 % DMA bytes, +0 %: the register loads cost what the DMA saved).  What is common to all of them is
+// the bytes a CU pulls out of L2 per MFMA (TCP_PENDING_STALL_CYCLES = 35 % of the kernel; the demand, 5.6 TB/s
+// chip-wide, is at the 6.4 TB/s MI355X_MICROARCH.md measures for LDS-DMA streams): only a larger block tile
+// would lower it, and at batch 1 there are not enough tiles for that.
 template <int TMT, int NSTG, int VARIANT = 0>
 __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
                                                         const float *__restrict__ bias_, const float *__restrict__ res_,
