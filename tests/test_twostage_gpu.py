@@ -117,3 +117,60 @@ def test_test_segnet_loop_writes_mat_files(device, tmp_path):
         m = scipy.io.loadmat(os.path.join(str(tmp_path), "%06d.mat" % i))
         assert m["labels"].shape == (120, 160) and m["labels_refined"].shape == (120, 160)
         assert np.array_equal(m["labels"], res[i]["labels"])
+
+
+def test_many_rois_vs_oracle(device):
+    """12 objects -> 12 ROIs: more crops than one cooperative farthest-point launch holds (8), so stage 2 runs as
+    several launches; label ids up to 12 + the two-way splits of stage 2.  Against the CPU oracle's test_sample."""
+    from oracle import glue_oracle as G
+    cfg.device = device
+    H, W = 240, 320
+    lab = np.zeros((H, W), np.int64)
+    k = 0
+    for by in range(3):
+        for bx in range(4):
+            k += 1
+            lab[20 + by * 70: 20 + by * 70 + 40 + 2 * k, 15 + bx * 78: 15 + bx * 78 + 30 + 3 * bx] = k
+    rng = np.random.default_rng(4)
+    centres = rng.standard_normal((k + 1, 64)).astype(np.float32)
+    centres /= np.linalg.norm(centres, axis=1, keepdims=True)
+    X = centres[lab.reshape(-1)] + np.float32(0.05) * rng.standard_normal((H * W, 64), dtype=np.float32)
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    feat = torch.from_numpy(X.astype(np.float32)).view(H, W, 64).permute(2, 0, 1)[None].contiguous()
+    fr = synth.rgbd_frame(91, H, W, 2, hole_fraction=0.0)
+    img, dep = torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"])
+    dep[:, 2] = 1.0 + torch.arange(W, dtype=torch.float32)[None, None, :] / W       # distinct mean depth per ROI
+    s1 = lambda i, l, d: feat
+    s2 = lambda i, l, d: torch.cat([e2e_stub_features(2000 + j, 224, 224, 2 + j % 2) for j in range(i.shape[0])])
+    want_label, want_refined = G.test_sample(img, dep, s1, s2, np.random.RandomState(RNG_SEED))
+    assert len(np.unique(want_label.numpy())) == 13
+    np.random.seed(RNG_SEED)
+    out_label, refined = TD.test_sample(dict(image_color=img, depth=dep), lambda i, l, d: s1(i, l, d).to(device),
+                                        lambda i, l, d: s2(i, l, d).to(device))
+    assert np.array_equal(out_label.numpy(), want_label.numpy())
+    assert np.array_equal(refined.numpy(), want_refined.numpy())
+    assert int(refined.max()) >= 12
+
+
+def test_bench_json_contract(device):
+    """bench.py prints ONE JSON line with the driver's keys plus the roofline / cpu_baseline objects."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-frames", "1",
+                          "--profile-steps", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "frames/s" and d["value"] > 1 and abs(d["value"] * d["ms_per_step"] - 1000.0) < 1.0
+    assert "workload" in d["config"] and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
