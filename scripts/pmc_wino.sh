@@ -1,10 +1,11 @@
 #!/bin/bash
-# PMC passes over the Winograd GEMM (dev).  Usage: scripts/pmc_wino.sh <outdir>
+# PMC passes over the Winograd GEMM (dev).  Usage (through gpurun): UOC_WINO_TMT=5 scripts/pmc_wino.sh <outdir>
+# Each pass is its own rocprofv3 run with --kernel-trace only.  NOTE: on this image the derived "*_sum" TCP/TCC
+# counters and the TA_* counters make rocprofv3 abort (signal 6) or hang until the timeout; the raw ones below work.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/$1; mkdir -p $O
-run() { n=$1; shift; timeout 150 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -- python $R/scripts/wino_one.py > $O/$n.log 2>&1; }
-run A SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
-run B SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD
-run C TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_TA_BUSY_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum
-run D TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_TAG_STALL_sum TCC_BUSY_sum TCC_CYCLE_sum
-find $O -name "*counter_collection.csv" | head; tail -3 $O/A.log
+run() { n=$1; shift; timeout 70 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/$n -- python $R/scripts/wino_one.py > $O/$n.log 2>&1; echo "$n rc=$?"; }
+run A SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
+run B SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD
+run E TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_REQUEST TCP_PENDING_STALL_CYCLES TCP_TCC_READ_REQ
+find $O -name "*counter_collection.csv" | head
