@@ -133,8 +133,9 @@ def main():
     def run(nsteps, gather):
         # frames of this rank: global indices rank*nsteps .. (weak scaling: fixed work per GPU)
         total = nsteps * world
-        maps = runner.run_sharded(total, lambda i: frame_fn(i - rank * nsteps), H, W, device, rank, world, gather,
-                                  force_collective=use_dist)
+        local = lambda i: frame_fn(i - rank * nsteps)
+        local.finish = frame_fn.finish          # clustering status check after the last frame (uoc_ms_check)
+        maps = runner.run_sharded(total, local, H, W, device, rank, world, gather, force_collective=use_dist)
         return maps.cpu()           # label-map block lands on the host inside the timed region
 
     # setup (never timed, independent of --warmup): one frame so that the native weight copies exist and

@@ -29,6 +29,7 @@ extern "C" {
 #define UOC_ENOMEM (-12)
 #define UOC_EHIP (-5)
 #define UOC_ENOENT (-2)
+#define UOC_ETIMEDOUT (-110)
 
 #define UOC_EMBED_DIM 64   /* channel count C the kernels are specialised for */
 #define UOC_MAX_SEEDS 128  /* num_seeds upper bound (reference default 100)   */
@@ -43,6 +44,10 @@ const char *uoc_last_error(void);
 /* Seed selection runs as ONE persistent cooperative launch with X resident on chip when the batch
  * fits the device (default); 0 forces the streaming one-launch-per-step kernel.  Same results. */
 int uoc_ms_set_persistent_fps(int on);
+/* The persistent kernel's grid-wide exchange spins with a bound; a block that gives up raises a sticky device
+ * flag and the call's outputs are then meaningless.  uoc_ms_check synchronises `stream`, reads and clears the
+ * flag: 0, or UOC_ETIMEDOUT.  The host mirrors call it at the points where they synchronise anyway. */
+int uoc_ms_check(void *stream);
 
 /* Scratch bytes the clustering entry points need for (batch, n, m). */
 size_t uoc_ms_workspace_bytes(int batch, int n, int m);

@@ -172,6 +172,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
 // (512-thread blocks, one per CU); every spin is bounded and sets *status on expiry.
 // Measured per step (480x640, 256 blocks): exchange ~3.2 us, compute + block reduce ~1.3 us.
 // -------------------------------------------------------------------------------------------
+__device__ int g_fps_timeout = 0;  // sticky: some block's bounded spin expired (read + cleared by uoc_ms_check)
+
 constexpr int FPP_THREADS = 512;
 constexpr int FPP_WAVES = FPP_THREADS / 64;
 constexpr int FPP_RS = 3;  // pixels per lane held in registers
@@ -334,7 +336,10 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
         } else {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > (1u << 22) || (((spins & 1023) == 0) && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            if (lane == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) {
+              __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(&g_fps_timeout, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             acc = ArgMax{0.f, 0};
             done = true;
           }
@@ -1071,6 +1076,20 @@ extern "C" {
 int uoc_ms_set_persistent_fps(int on) {
   g_fps_persistent = on ? 1 : 0;
   return UOC_OK;
+}
+
+int uoc_ms_check(void *stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int flag = 0;
+  UOC_HIP_CHECK(hipMemcpyFromSymbolAsync(&flag, HIP_SYMBOL(g_fps_timeout), sizeof(int), 0, hipMemcpyDeviceToHost, st));
+  UOC_HIP_CHECK(hipStreamSynchronize(st));
+  if (!flag) return UOC_OK;
+  const int zero = 0;
+  UOC_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_fps_timeout), &zero, sizeof(int), 0, hipMemcpyHostToDevice, st));
+  UOC_HIP_CHECK(hipStreamSynchronize(st));
+  set_error("farthest-point sampling: a block's grid-wide exchange timed out (blocks not co-resident?); results of "
+            "the affected clustering call are invalid");
+  return UOC_ETIMEDOUT;
 }
 
 size_t uoc_ms_workspace_bytes(int batch, int n, int m) {

@@ -76,6 +76,7 @@ def clustering_features(features, num_seeds=100):
     labels, indices = _cluster_device(features, num_seeds)
     B, _, h, w = features.shape
     out_label = labels.view(B, h, w).float().cpu()
+    _check_clustering(labels.device)
     return out_label, [indices[j].long().cpu() for j in range(B)]
 
 
@@ -107,7 +108,14 @@ def filter_labels_depth(labels, depth, threshold):
 
 def _read_table(table_dev: torch.Tensor) -> _native.RoiTable:
     host = table_dev.cpu().numpy().tobytes()      # one small D2H (2.5 KB); synchronises the stream
+    _check_clustering(table_dev.device)
     return _native.RoiTable.from_buffer_copy(host)
+
+
+def _check_clustering(dev):
+    """Raise if a clustering launch since the last check reported a timed-out grid exchange (uoc_ms_check)."""
+    with torch.cuda.device(dev):
+        _native.check(_native.lib().uoc_ms_check(_native.stream_ptr(dev)), "uoc_ms_check")
 
 
 def _build_rois(lab0: torch.Tensor, z_plane_ptr, H, W, dev, threshold=DEPTH_FILTER):
@@ -268,6 +276,7 @@ def _run_frame(sample, network, network_crop, depth_threshold, return_device=Fal
             out_label_refined = refined.view(1, H, W)
     if return_device:
         return labels.view(B, H, W), out_label_refined
+    _check_clustering(dev)
     out_label = labels.view(B, H, W).float().cpu()
     if out_label_refined is not None:
         out_label_refined = out_label_refined.float().cpu()

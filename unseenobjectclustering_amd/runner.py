@@ -41,6 +41,8 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     for i in range(lo, hi):
         np.random.seed(frame_rng_seed(i))
         block[i - lo] = frame_fn(i).to(torch.uint8)
+    if hasattr(frame_fn, "finish") and device.type == "cuda":
+        frame_fn.finish(device)
     if (world == 1 and not force_collective) or not gather:
         return block[:hi - lo]
     full = torch.empty((world * per, height, width), dtype=torch.uint8, device=device)
@@ -51,9 +53,12 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
 def two_stage_frame_fn(samples, network, network_crop):
     """frame_fn over pre-uploaded samples: final label map = refined map if stage 2 produced one,
     else the stage-1 map (what test_segnet stores as labels_refined, test_dataset.py:324-327)."""
-    from .fcn.test_dataset import _run_frame, DEPTH_FILTER
+    from .fcn.test_dataset import _run_frame, _check_clustering, DEPTH_FILTER
 
     def fn(i: int) -> torch.Tensor:
         out, refined = _run_frame(samples[i % len(samples)], network, network_crop, DEPTH_FILTER, return_device=True)
         return (refined if refined is not None else out)[0]
+    # every frame checks the clustering status once after stage 1 (a sticky device flag, so a stage-2 failure
+    # surfaces at the next frame); fn.finish() is the check after the last frame
+    fn.finish = lambda dev: _check_clustering(dev)
     return fn

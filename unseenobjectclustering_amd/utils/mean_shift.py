@@ -122,7 +122,10 @@ def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine"
             raise _native.NativeError("X must be on a ROCm device (no CPU fallback)")
         Xb = to_planes(Xb.float())
     labels, indices = cluster_batch(Xb, [first], kappa, num_seeds, max_iters)
-    return labels[0].long(), indices[0].long().cpu()
+    idx = indices[0].long().cpu()            # synchronises; then ask whether the grid exchange completed
+    with torch.cuda.device(labels.device):
+        _native.check(_native.lib().uoc_ms_check(_native.stream_ptr(labels.device)), "uoc_ms_check")
+    return labels[0].long(), idx
 
 
 def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=None, num_init_seeds=None,
