@@ -89,6 +89,19 @@ def cpu_baseline_subprocess(frames, limit_s=240):
                 "sample": f"timed out after {limit_s}s on this host"}
 
 
+def frame_roofline(rois, sec_per_frame):
+    """Whole-frame position against both rooflines from SURVEY.md 8(d)'s ALGORITHMIC per-frame work (the
+    reference's formulation: farthest-point sampling re-reads X every step, convolutions are direct):
+    clustering 8.98 GB + 1.43 GB per ROI; backbone 424.4 GFLOP + 69.3 per ROI, clustering 86.5 GFLOP + 14.1 per ROI."""
+    gb = 8.98 + 1.43 * rois
+    gflop = 424.4 + 86.5 + (69.3 + 14.1) * rois
+    return {"rois_per_frame": round(rois, 2), "algorithmic_gb": round(gb, 2), "algorithmic_gflop": round(gflop, 1),
+            "hbm_frac": round(gb / sec_per_frame / PEAK_HBM_GBS, 4),
+            "mfma_frac": round(gflop / 1e3 / sec_per_frame / PEAK_FP32_TFLOPS, 4),
+            "note": "algorithmic bytes/flops of SURVEY 8(d) per frame over the measured frame time; the on-chip "
+                    "sampling kernel and Winograd move/execute less than the algorithmic amounts"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,6 +174,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     objects = float(np.mean([int(m.max()) for m in maps[:K]]))
+    rois = float(np.mean(frame_fn.roi_counts[-K:])) if frame_fn.roi_counts else 0.0
     pcie = None
     if rank == 0 and world == 1 and os.environ.get("UOC_BENCH_PCIE") == "1":
         # informative only (never `value`): the same frames, but uploaded from pageable host memory per frame
@@ -230,9 +244,9 @@ def main():
             "config": {"workload": "configs[3]: full two-stage (crop-and-refine) segmentation, 640x480 RGB-D, batch 1"
                                    + ("" if world == 1 else f"; configs[4]: frames sharded over {world} GPUs + RCCL all_gather"),
                        "frame": "640x480", "seeds": 100, "iters": 10, "crop": 224,
-                       "mean_final_objects": round(objects, 2), "frames_per_gpu": K,
+                       "mean_final_objects": round(objects, 2), "mean_rois": round(rois, 2), "frames_per_gpu": K,
                        **({"pcie_inclusive_frames_per_s": pcie} if pcie is not None else {})},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "frame_roofline": frame_roofline(rois, dt / K), "cpu_baseline": cpu, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -172,5 +172,8 @@ def test_bench_json_contract(device):
     assert "workload" in d["config"] and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    f = d["frame_roofline"]
+    assert 0 < f["hbm_frac"] < 1 and 0 < f["mfma_frac"] < 1 and f["rois_per_frame"] >= 1
+    assert abs(f["algorithmic_gb"] - (8.98 + 1.43 * f["rois_per_frame"])) < 0.02
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c

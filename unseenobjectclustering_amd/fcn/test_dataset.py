@@ -28,6 +28,7 @@ DEPTH_FILTER = 0.8    # :252
 MAX_LABELS = 128
 
 _roi_ws = {}
+LAST_FRAME_STATS = {"rois": 0}      # number of stage-1 ROIs of the most recent frame (measurement bookkeeping)
 
 
 def _device():
@@ -268,6 +269,7 @@ def _run_frame(sample, network, network_crop, depth_threshold, return_device=Fal
     out_label_refined = None
     if network_crop is not None:
         K = int(_read_table(table).K)
+        LAST_FRAME_STATS["rois"] = K
         if K > 0:
             rgb_crop, mask_crop, depth_crop = _crop(image, depth, labels[0], table, K, H, W, dev)
             features_crop = network_crop(rgb_crop, mask_crop, depth_crop)

@@ -53,11 +53,13 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
 def two_stage_frame_fn(samples, network, network_crop):
     """frame_fn over pre-uploaded samples: final label map = refined map if stage 2 produced one,
     else the stage-1 map (what test_segnet stores as labels_refined, test_dataset.py:324-327)."""
-    from .fcn.test_dataset import _run_frame, _check_clustering, DEPTH_FILTER
+    from .fcn.test_dataset import _run_frame, _check_clustering, DEPTH_FILTER, LAST_FRAME_STATS
 
     def fn(i: int) -> torch.Tensor:
         out, refined = _run_frame(samples[i % len(samples)], network, network_crop, DEPTH_FILTER, return_device=True)
+        fn.roi_counts.append(LAST_FRAME_STATS["rois"])
         return (refined if refined is not None else out)[0]
+    fn.roi_counts = []          # stage-1 ROIs per processed frame (the bench derives the algorithmic work from it)
     # every frame checks the clustering status once after stage 1 (a sticky device flag, so a stage-2 failure
     # surfaces at the next frame); fn.finish() is the check after the last frame
     fn.finish = lambda dev: _check_clustering(dev)
