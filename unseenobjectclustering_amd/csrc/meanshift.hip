@@ -383,6 +383,12 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
 // float4: xa[v] = X[p=t][16v+4q..], xb[r] = X[p=4q+r][4t..].  W (122.9 MB in the reference) never
 // exists in memory.  Wave partials are reduced through LDS; block partials go to HBM and are
 // reduced (fixed order) + L2-normalised by hc_finalize_kernel.
+// Two other formulations were built, verified and measured on MI355X against this one (113 us per iteration
+// incl. finalize at 480x640): "seed tile per wave", Z fragments and a 16x64 accumulator in registers, no LDS, 4
+// waves/SIMD, every wave loading the pixels itself: 137 us (7x the L1/L2 traffic); the same with the pixels
+// streamed once per block through an LDS-DMA ring (94 VGPRs, 4 waves/SIMD): 113-117 us.  Without any exp()
+// that kernel takes 100 us, with __expf 104 us: the three land on the same ~2/3 of the fp32 MFMA peak as the
+// convolution kernels, so the simplest one stays.
 // -------------------------------------------------------------------------------------------
 #ifndef UOC_EXP
 #define UOC_EXP expf
