@@ -153,8 +153,12 @@ def main():
 
     # setup (never timed, independent of --warmup): one frame so that the native weight copies exist and
     # the conv autotuner has chosen its tile family / staging variant for every layer shape
-    np.random.seed(runner.frame_rng_seed(0))
-    frame_fn(0)
+    # ... for EVERY distinct frame: the stage-2 batch size (number of ROIs) differs per frame, and a new batch
+    # size means first-use work (kernel instantiations loading, a tile-height variant's attributes, a tuner
+    # lookup) that must not land in the timed region of a fresh process
+    for i in range(distinct):
+        np.random.seed(runner.frame_rng_seed(i))
+        frame_fn(i)
     torch.cuda.synchronize()
     print(f"[bench] rank {rank}: nets built, {distinct} frames resident, warming up", file=sys.stderr, flush=True)
     if args.warmup > 0:
