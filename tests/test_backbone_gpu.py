@@ -103,6 +103,19 @@ def test_network_vs_oracle_fresh_input(device):
     assert (got - want).abs().max().item() < EMBED_TOL
 
 
+@pytest.mark.parametrize("hw", [(77, 93), (50, 131)])
+def test_network_odd_sizes_vs_oracle(device, hw):
+    """Sizes that are not multiples of 8 (the reference's conv arithmetic handles any H x W): odd stem / pool /
+    stride-2 outputs, partial Winograd tiles in every dilation phase, non-integer upsampling ratios."""
+    net, sd = _net(3, device)
+    fr = synth.rgbd_frame(13, hw[0], hw[1], 2)
+    img, dep = torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"])
+    want = BO.segnet_forward(sd, img, dep)
+    got = net(img.to(device), None, dep.to(device)).cpu()
+    assert got.shape == want.shape == (1, 64, hw[0], hw[1])
+    assert (got - want).abs().max().item() < EMBED_TOL
+
+
 def test_network_interface(device):
     net, sd = _net(1, device)
     assert set(net.state_dict().keys()) == set(sd.keys())
