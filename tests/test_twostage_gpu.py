@@ -177,3 +177,25 @@ def test_bench_json_contract(device):
     assert abs(f["algorithmic_gb"] - (8.98 + 1.43 * f["rois_per_frame"])) < 0.02
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+
+
+def test_batch_of_two_and_no_crop_network(device):
+    """test_sample on a batch of 2 (test_dataset.py:247-261: every item is clustered and depth-filtered, only item
+    0 is refined) and with network_crop=None (returns (out_label, None))."""
+    from oracle import glue_oracle as G
+    cfg.device = device
+    frs = [synth.rgbd_frame(s, 120, 160, 3) for s in (81, 82)]
+    img = torch.from_numpy(np.concatenate([f["image_color"] for f in frs]))
+    dep = torch.from_numpy(np.concatenate([f["depth"] for f in frs]))
+    s1 = lambda i, l, d: torch.cat([e2e_stub_features(300 + k, 120, 160, 4) for k in range(i.shape[0])])
+    s2 = lambda i, l, d: torch.cat([e2e_stub_features(400 + k, 224, 224, 2) for k in range(i.shape[0])])
+    want_label, want_refined = G.test_sample(img, dep, s1, s2, np.random.RandomState(RNG_SEED))
+    np.random.seed(RNG_SEED)
+    out_label, refined = TD.test_sample(dict(image_color=img, depth=dep), lambda i, l, d: s1(i, l, d).to(device),
+                                        lambda i, l, d: s2(i, l, d).to(device))
+    assert out_label.shape == (2, 120, 160) and refined.shape == (2, 120, 160) and float(refined[1].abs().max()) == 0.0
+    assert np.array_equal(out_label.numpy(), want_label.numpy())
+    assert np.array_equal(refined.numpy(), want_refined.numpy())
+    np.random.seed(RNG_SEED)
+    out2, none = TD.test_sample(dict(image_color=img, depth=dep), lambda i, l, d: s1(i, l, d).to(device), None)
+    assert none is None and np.array_equal(out2.numpy(), want_label.numpy())

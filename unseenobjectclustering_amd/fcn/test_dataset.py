@@ -231,7 +231,8 @@ def match_label_crop(initial_masks, labels_crop, out_label_crop, rois, depth_cro
 
 
 def test_sample(sample, network, network_crop):
-    """test_dataset.py:232-267: (out_label [B,H,W] float32 CPU, out_label_refined [1,H,W] float32 CPU or None)."""
+    """test_dataset.py:232-267: (out_label [B,H,W] float32 CPU, out_label_refined [B,H,W] float32 CPU — only item 0 is
+    refined, the rest stays zero, as in the reference — or None)."""
     return _run_frame(sample, network, network_crop, DEPTH_FILTER)
 
 
@@ -276,6 +277,10 @@ def _run_frame(sample, network, network_crop, depth_threshold, return_device=Fal
             labels_crop, _ = _cluster_device(features_crop)              # K fields, one launch set
             refined, _ = _match(labels_crop, mask_crop, depth_crop, table, K, H, W, dev)
             out_label_refined = refined.view(1, H, W)
+            if B > 1:    # match_label_crop returns zeros_like(initial_masks) with only item 0 painted (:153,:176-177)
+                full = torch.zeros((B, H, W), dtype=refined.dtype, device=dev)
+                full[0] = out_label_refined[0]
+                out_label_refined = full
     if return_device:
         return labels.view(B, H, W), out_label_refined
     _check_clustering(dev)
