@@ -163,6 +163,16 @@ __device__ __forceinline__ void wglds16(const float *g, unsigned lds_dst) {
       : "v"(g), "s"(lds_dst)
       : "memory");
 }
+// the same with the address split into a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset:
+// no VALU instruction per load (MFMA issue shares its port with the VALU: scripts/mfma_patterns.hip)
+__device__ __forceinline__ void wglds16s(const float *base, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(base), "s"(lds_dst)
+      : "memory");
+}
 template <int N>
 __device__ __forceinline__ void wwait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -211,7 +221,6 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
   const int cpt = Cin / WBK;
   const int nit = 8 * cpt;  // >= 8 > NSTG
 
-  const float *zero = reinterpret_cast<const float *>(g_wino_zero);
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char *)smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -221,23 +230,27 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
   // ---- DMA descriptors ---------------------------------------------------------------------------
   constexpr int NISS = NPASS;  // DMA instructions per wave and chunk: 8 waves x 8 rows per pass
   static_assert((NSTG - 1) * NISS < 64, "vmcnt range");
-  int d_r0[NISS], d_off[NISS], d_kind[NISS];  // kind: bit0 = U row, bit1 = frequency group, 4 = zero page
+  // A pass is 8 rows of ONE kind (SEG and BM are multiples of 16): kind (bit0 = U row, bit1 = frequency group)
+  // is wave-uniform, the lane keeps a 32-bit byte offset.  Tile rows beyond NT read the last valid row instead
+  // of a zero page: their products land in accumulators of tiles the epilogue never stores.
+  int d_r0[NISS], d_kind[NISS];
+  unsigned d_off[NISS];
 #pragma unroll
   for (int j = 0; j < NISS; ++j) {
     int r0 = j * RPP + wave * 8;
     if (r0 >= R) r0 = R - 8;
     d_r0[j] = r0;
+    const int fr0 = r0 >= SEG ? 1 : 0;
+    d_kind[j] = ((r0 - fr0 * SEG) >= BM ? 1 : 0) | (fr0 << 1);
     const int r = r0 + (lane >> 3);
     const int c = (lane & 7) ^ ((r >> 1) & 7);
-    const int fr = r >= SEG ? 1 : 0;
-    const int rr = r - fr * SEG;
+    const int rr = r - fr0 * SEG;
     if (rr >= BM) {
-      d_kind[j] = 1 | (fr << 1);
-      d_off[j] = (n0 + rr - BM) * WBK + 4 * c;
+      d_off[j] = (unsigned)(((n0 + rr - BM) * WBK + 4 * c) * sizeof(float));
     } else {
-      const int tau = m0 + rr;
-      d_kind[j] = (tau < NT) ? (fr << 1) : 4;
-      d_off[j] = tau * WBK + 4 * c;
+      int tau = m0 + rr;
+      if (tau >= NT) tau = NT - 1;
+      d_off[j] = (unsigned)((tau * WBK + 4 * c) * sizeof(float));
     }
   }
   // running (frequency-pair e, cin chunk cc) of the chunk being issued
@@ -252,8 +265,7 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
     _Pragma("unroll") for (int j = 0; j < NISS; ++j) {                                                  \
       const int kd = d_kind[j];                                                                         \
       const float *b_ = (kd & 1) ? ((kd & 2) ? bu1_ : bu0_) : ((kd & 2) ? bv1_ : bv0_);                 \
-      const float *src = (kd & 4) ? zero : b_ + d_off[j];                                               \
-      wglds16(src, lds_base + (unsigned)(((STG)*STAGE + d_r0[j] * WBK) * sizeof(float)));               \
+      wglds16s(b_, d_off[j], lds_base + (unsigned)(((STG)*STAGE + d_r0[j] * WBK) * sizeof(float)));     \
     }                                                                                                   \
     if (++q_cc == cpt) {                                                                                \
       q_cc = 0;                                                                                         \
