@@ -547,41 +547,62 @@ __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__rest
 
 // Z[seed] = normalize(sum_blk partial[blk][seed])  (F.normalize, eps 1e-12; mean_shift.py:107)
 // partial [b][blk][NH][rows][64] -> Z [b][NH][m][64], the norm runs over all NH * 64 channels.
+// One block per seed: 16 lanes x float4 cover a 256-byte row, so a wave reads the rows of 4 blocks per load and
+// the 4 waves keep 64 rows in flight per step (4 independent accumulators); fixed summation order.
 template <int NH>
 __global__ __launch_bounds__(256) void hc_finalize_kernel(const float *__restrict__ partial, int nblk, int rows,
                                                           int m, float *__restrict__ Z) {
   const int b = blockIdx.y, seed = blockIdx.x;
-  const int c = threadIdx.x & 63, w = threadIdx.x >> 6;
-  __shared__ float red[NH][4][C];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c4 = lane & 15, sub = lane >> 4;
+  const int slot = w * 4 + sub;  // 0..15: which of 16 concurrently read block rows
+  __shared__ float4 red[NH][4][16];
+  auto add4 = [](float4 a, float4 c) { return make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w); };
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
-    const float *src = partial + (((size_t)b * nblk * NH + h) * rows + seed) * C + c;
+    const float *src = partial + (((size_t)b * nblk * NH + h) * rows + seed) * C + 4 * c4;
     const size_t bs = (size_t)NH * rows * C;  // block stride
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int blk = w;
-    for (; blk + 12 < nblk; blk += 16) {
-      s0 += src[(size_t)blk * bs];
-      s1 += src[(size_t)(blk + 4) * bs];
-      s2 += src[(size_t)(blk + 8) * bs];
-      s3 += src[(size_t)(blk + 12) * bs];
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    auto ld = [&](int blk) { return *reinterpret_cast<const float4 *>(src + (size_t)blk * bs); };
+    int blk = slot;
+    for (; blk + 48 < nblk; blk += 64) {
+      s0 = add4(s0, ld(blk));
+      s1 = add4(s1, ld(blk + 16));
+      s2 = add4(s2, ld(blk + 32));
+      s3 = add4(s3, ld(blk + 48));
     }
-    for (; blk < nblk; blk += 4) s0 += src[(size_t)blk * bs];
-    red[h][w][c] = (s0 + s1) + (s2 + s3);
+    for (; blk < nblk; blk += 16) s0 = add4(s0, ld(blk));
+    float4 s = add4(add4(s0, s1), add4(s2, s3));
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+      s.x += __shfl_xor(s.x, off);
+      s.y += __shfl_xor(s.y, off);
+      s.z += __shfl_xor(s.z, off);
+      s.w += __shfl_xor(s.w, off);
+    }
+    if (sub == 0) red[h][w][c4] = s;
   }
   __syncthreads();
-  if (w == 0) {
-    float v[NH];
+  if (w == 0) {  // all 64 lanes take part in the shuffles; lanes with sub != 0 mirror sub 0
+    float4 v[NH];
     float ss = 0.f;
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      v[h] = (red[h][0][c] + red[h][1][c]) + (red[h][2][c] + red[h][3][c]);
-      ss = h == 0 ? v[h] * v[h] : fmaf(v[h], v[h], ss);
+      v[h] = add4(add4(red[h][0][c4], red[h][1][c4]), add4(red[h][2][c4], red[h][3][c4]));
+      ss = fmaf(v[h].x, v[h].x, ss);
+      ss = fmaf(v[h].y, v[h].y, ss);
+      ss = fmaf(v[h].z, v[h].z, ss);
+      ss = fmaf(v[h].w, v[h].w, ss);
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);
+    for (int off = 8; off >= 1; off >>= 1) ss += __shfl_xor(ss, off);  // over the 16 channel groups
     const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+    if (sub == 0) {
 #pragma unroll
-    for (int h = 0; h < NH; ++h) Z[(((size_t)b * NH + h) * m + seed) * C + c] = v[h] / nrm;
+      for (int h = 0; h < NH; ++h)
+        *reinterpret_cast<float4 *>(Z + (((size_t)b * NH + h) * m + seed) * C + 4 * c4) =
+            make_float4(v[h].x / nrm, v[h].y / nrm, v[h].z / nrm, v[h].w / nrm);
+    }
   }
 }
 
