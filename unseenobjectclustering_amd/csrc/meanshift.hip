@@ -387,8 +387,10 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
 // incl. finalize at 480x640): "seed tile per wave", Z fragments and a 16x64 accumulator in registers, no LDS, 4
 // waves/SIMD, every wave loading the pixels itself: 137 us (7x the L1/L2 traffic); the same with the pixels
 // streamed once per block through an LDS-DMA ring (94 VGPRs, 4 waves/SIMD): 113-117 us.  Without any exp()
-// that kernel takes 100 us, with __expf 104 us: the three land on the same ~2/3 of the fp32 MFMA peak as the
-// convolution kernels, so the simplest one stays.
+// that kernel takes 100 us, with __expf 104 us.  A fourth, register-blocked one (two seed tiles per wave resident
+// in registers, two pixel tiles per 16 LDS reads = 0.125 reads per MFMA, 3 waves/SIMD, two-phase software
+// pipeline): 109 us.  All four sit at ~56 % of the fp32 MFMA peak (12 % of the MFMAs are the padding of 100 seeds
+// to 7 tiles), so the simplest one stays; no single bound was found (clock 2.4 GHz, 850 W under this kernel).
 // -------------------------------------------------------------------------------------------
 #ifndef UOC_EXP
 #define UOC_EXP expf
