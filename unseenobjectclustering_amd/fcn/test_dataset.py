@@ -109,7 +109,6 @@ def filter_labels_depth(labels, depth, threshold):
 
 def _read_table(table_dev: torch.Tensor) -> _native.RoiTable:
     host = table_dev.cpu().numpy().tobytes()      # one small D2H (2.5 KB); synchronises the stream
-    _check_clustering(table_dev.device)
     return _native.RoiTable.from_buffer_copy(host)
 
 
@@ -181,22 +180,25 @@ def _match(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev):
     S = cfg.TRAIN.SYN_CROP_SIZE
     L = _native.lib()
     ws = _ws(dev)
-    keep = torch.empty((K, MAX_LABELS), dtype=torch.int32, device=dev)
-    meanz = torch.empty((K,), dtype=torch.float32, device=dev) if depth_crops is not None else None
+    # keep table and mean depths share one buffer (one D2H), paint order and id map another (one H2D)
+    stats = torch.empty((K * MAX_LABELS + K,), dtype=torch.int32, device=dev)
+    keep = stats[:K * MAX_LABELS].view(K, MAX_LABELS)
+    meanz = stats[K * MAX_LABELS:].view(torch.float32) if depth_crops is not None else None
     with torch.cuda.device(dev):
         rc = L.uoc_roi_match_stats(_native.ptr(labels_crop_i32), _native.ptr(mask_crops), _native.ptr(depth_crops), K, S,
                                    _native.ptr(keep), _native.ptr(meanz), _native.ptr(ws), ws.numel(),
                                    _native.stream_ptr(dev))
     _native.check(rc, "uoc_roi_match_stats")
-    keep_h = keep.cpu().numpy()
+    stats_h = stats.cpu()
+    keep_h = stats_h[:K * MAX_LABELS].view(K, MAX_LABELS).numpy()
     if meanz is not None:
-        sort_key = meanz.cpu()
+        sort_key = stats_h[K * MAX_LABELS:].view(torch.float32)
     else:       # :138-146 roi_size = (y_max - y_min + 1) * (x_max - x_min + 1), float32 like the reference's rois
         box = torch.tensor(np.ctypeslib.as_array(_read_table(table).box)[:K].astype(np.float32))
         sort_key = (box[:, 3] - box[:, 1] + 1) * (box[:, 2] - box[:, 0] + 1)
     order, mapping = _order_and_map(keep_h, sort_key)
-    order_d = torch.from_numpy(order).to(dev)
-    map_d = torch.from_numpy(mapping).to(dev)
+    plan = torch.from_numpy(np.concatenate([order.reshape(-1), mapping.reshape(-1)]).astype(np.int32)).to(dev)
+    order_d, map_d = plan[:K], plan[K:]
     refined = torch.empty((H * W,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
         rc = L.uoc_roi_paste(_native.ptr(labels_crop_i32), _native.ptr(table), _native.ptr(map_d), _native.ptr(order_d),
@@ -324,6 +326,7 @@ def test_segnet(test_loader, network, output_dir, network_crop):
         prediction_dev = labels_dev.reshape(labels_dev.shape[-2:]) if labels_dev.shape[0] == 1 else labels_dev[0]
         refined_2d = refined_dev[0] if refined_dev is not None else prediction_dev
         prediction = labels_dev.float().cpu().squeeze().numpy()
+        _check_clustering(labels_dev.device)
         prediction_refined = refined_dev.float().cpu().squeeze().numpy() if refined_dev is not None else prediction.copy()
         result = {"labels": prediction, "labels_refined": prediction_refined, "filename": sample.get("filename", "")}
         if "label" in sample:
