@@ -44,6 +44,28 @@ def test_argument_validation_without_gpu():
     assert b"null" in lib.uoc_last_error().lower()
     rc = lib.uoc_ms_seed_components(None, 1, 1000, 0.04, None, None, None)
     assert rc == -22
+    # 128-d entry points: halves in {1, 2}; the 2-plane workspace is larger
+    assert lib.uoc_ms_workspace_bytes_wide(1, 50176, 100, 2) > lib.uoc_ms_workspace_bytes_wide(1, 50176, 100, 1) > 0
+    assert lib.uoc_ms_workspace_bytes_wide(1, 50176, 100, 1) == lib.uoc_ms_workspace_bytes(1, 50176, 100)
+    assert lib.uoc_ms_workspace_bytes_wide(1, 50176, 100, 3) == 0
+    rc = lib.uoc_ms_cluster_wide(None, 3, 1, 100, 100, 20.0, 10, 0.04, None, None, None, None, None, None, 0, None)
+    assert rc == -22 and b"halves" in lib.uoc_last_error().lower()
+    # network handle: unknown mode rejected, embedding width per mode, parameter intake is host-only
+    h = ctypes.c_void_p()
+    assert lib.uoc_net_create_mode(ctypes.byref(h), 9) == -22
+    for mode, dim in ((0, 64), (1, 64), (2, 64), (3, 64), (4, 128)):
+        h = ctypes.c_void_p()
+        assert lib.uoc_net_create_mode(ctypes.byref(h), mode) == 0
+        assert lib.uoc_net_embed_dim(h) == dim
+        assert lib.uoc_net_workspace_bytes(h, 1, 480, 640) > 100 << 20
+        arr = (ctypes.c_float * 4)(1, 2, 3, 4)
+        assert lib.uoc_net_load_param(h, b"fcn.resnet34_8s.fc.bias", arr, 4) == 0
+        assert lib.uoc_net_forward(h, None, None, 1, 64, 64, None, None, 0, None) == -22      # not finalized
+        assert lib.uoc_net_destroy(h) == 0
+    # evaluation and glue entries validate their pointers first
+    assert lib.uoc_eval_workspace_bytes(480, 640) >= 2 * 480 * 640 * 4
+    assert lib.uoc_eval_pair_stats(None, None, 480, 640, 3, None, None, 0, None) == -22
+    assert lib.uoc_roi_crop(None, None, None, 480, 640, None, 1, 224, None, None, None, None) == -22
 
 
 def test_product_path_refuses_cpu_tensors():
