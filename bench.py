@@ -1,29 +1,44 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: end-to-end two-stage RGB-D segmentation at 640x480.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W            (N > 1)
+    python bench.py --gpus N --steps K --warmup W          weak scaling: K frames per GPU
+    python bench.py --gpus N --frames F --warmup W         strong scaling: F frames sharded in contiguous blocks of
+                                                           ceil(F/N) (BASELINE.json configs[4]: --frames 1024 --gpus 8)
+
+For N > 1 either launch it under torch.distributed.run (the driver does; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+are read from the environment) or call it bare: without WORLD_SIZE in the environment `python bench.py --gpus N`
+re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`.
 
 One step = one synthetic 640x480 RGB-D frame (batch 1) through the whole path on one GPU:
 RGB-D ResNet34-8s embedding -> mean-shift (100 seeds, 10 iterations) -> depth filter -> ROI
 crops -> second network on the K crops -> K batched mean-shifts -> match/paste (BASELINE.json
 configs[3]; configs[4] = the same sharded over N GPUs with one RCCL all_gather of the label maps).
-Inputs are resident in HBM when the timed region starts; the timed region includes the D2H of
+Global frame g is `synth.palette_frame(10000 + g)` with the first-seed RNG seeded by `runner.frame_rng_seed(g)` on
+every rank count, so the gathered [F,480,640] uint8 block does not depend on the sharding.
+Inputs are resident in HBM when the timed region starts; the timed region includes the (collective and the) D2H of
 the label-map block.  Weights are the calibrated synthetic set (synth.calibrated_state_dict):
 random-init backbone of the reference architecture + closed-form calibration so that synthetic
 frames segment into their objects and stage 2 really runs (K ~ 6-8 ROIs per frame).
 
-Prints ONE JSON line (rank 0).  `roofline` = the kernel class with the largest share of GPU time
-in a profiled pass over the same frames (HIP events on the launch stream, csrc/prof.hip);
-`cpu_baseline` = the CPU oracle (torch CPU restatement of the reference path) on a bounded sample.
+Prints ONE JSON line (rank 0).  Besides the contract fields:
+  roofline      the kernel class with the largest share of GPU time in a profiled pass over the same frames (HIP
+                events on the launch stream, csrc/prof.hip)
+  cpu_baseline  the CPU oracle (torch-CPU restatement of the reference path) on the FIRST frames of the timed set,
+                same frames / seeds / weights as the GPU leg (bounded sample)
+  parity        the GPU label maps of those frames against the oracle's (agreement up to label permutation)
+  sustained     the same block of frames looped for >= 10 s, with clock / power samples (N = 1)
+  pcie_inclusive_frames_per_s   the timed frames again, inputs uploaded per frame from pageable host memory (N = 1)
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,59 +49,150 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 H, W = 480, 640
+FIRST_PALETTE_SEED = 10_000
 PEAK_HBM_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_FP32_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 MFMA (= vector) peak
 
 
-def make_samples(count, first_seed, device):
+# ----------------------------------------------------------------------------------------------------------------
+# workload: global frame index -> inputs
+# ----------------------------------------------------------------------------------------------------------------
+def _palette(g):
     from unseenobjectclustering_amd import synth
-    out = []
-    for i in range(count):
-        s = first_seed + i
-        fr = synth.palette_frame(s, H, W, 5 + s % 3)
-        out.append(dict(image_color=torch.from_numpy(fr["image_color"]).to(device),
-                        depth=torch.from_numpy(fr["depth"]).to(device)))
-    return out
+    s = FIRST_PALETTE_SEED + g
+    fr = synth.palette_frame(s, H, W, 5 + s % 3)
+    return fr["image_color"], fr["depth"]
 
 
-def cpu_baseline(frames):
-    """The oracle's two-stage test_sample on the host cores (torch CPU ops = the reference's ops)."""
+def host_frames(lo, hi):
+    """Synthetic inputs of the global frames [lo, hi) as numpy arrays (a process pool for big blocks)."""
+    idx = list(range(lo, hi))
+    if len(idx) > 32:
+        import multiprocessing as mp
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 1
+        with mp.get_context("fork").Pool(max(1, min(32, ncpu // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))) as pool:
+            return pool.map(_palette, idx, chunksize=4)
+    return [_palette(g) for g in idx]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU leg: the oracle on the first frames of the timed set (child process)
+# ----------------------------------------------------------------------------------------------------------------
+def cpu_model_name():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def cpu_baseline(frames, out_path):
+    """The oracle's two-stage test_sample on the host cores (torch CPU ops = the reference's ops), on global frames
+    0..frames-1 of the benchmark set with the runner's per-frame RNG seeds.  Label maps go to `out_path` (npz)."""
     from oracle import backbone_oracle as BO, glue_oracle as GO
-    from unseenobjectclustering_amd import synth
+    from unseenobjectclustering_amd import runner, synth
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(ncpu, 64)))
+    torch.set_num_threads(max(1, ncpu))
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
     net = lambda img, label, depth: BO.segnet_forward(sd, img, depth)
-    inputs = [synth.palette_frame(i, H, W, 5 + i % 3) for i in range(frames)]
+    inputs = host_frames(0, frames)
+    maps, stage1 = [], []
     t0 = time.time()
-    done = 0
-    for i, fr in enumerate(inputs):
-        GO.test_sample(torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"]), net, net,
-                       np.random.RandomState(3 + i))
-        done += 1
+    for g, (img, dep) in enumerate(inputs):
+        out, refined = GO.test_sample(torch.from_numpy(img), torch.from_numpy(dep), net, net,
+                                      np.random.RandomState(runner.frame_rng_seed(g)))
+        maps.append((refined if refined is not None else out)[0].numpy().astype(np.int32))
+        stage1.append(out[0].numpy().astype(np.int32))
         if time.time() - t0 > 30.0:          # bounded sample: stop after ~30 s of CPU work
             break
     dt = time.time() - t0
-    return {"value": round(done / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{done} synthetic 640x480 RGB-D frames, full two-stage path, oracle/ (torch CPU fp32)"}
+    done = len(maps)
+    if out_path:
+        np.savez_compressed(out_path, final=np.stack(maps), stage1=np.stack(stage1))
+    return {"value": round(done / dt, 4), "unit": "frames/s", "cores": torch.get_num_threads(), "host_cores": ncpu,
+            "cpu_model": cpu_model_name(), "kind": "port",
+            "sample": f"global frames 0..{done - 1} of the GPU leg's set (same inputs, RNG seeds and weights), full "
+                      f"two-stage path, oracle/ (torch CPU fp32, {torch.get_num_threads()} threads)"}
 
 
-def cpu_baseline_subprocess(frames, limit_s=240):
+def cpu_baseline_subprocess(frames, out_path, limit_s=300):
     """Runs the CPU leg in a child process so a slow host can never stall the GPU benchmark."""
-    import subprocess
+    fail = {"value": None, "unit": "frames/s", "cores": None, "cpu_model": cpu_model_name(), "kind": "port"}
     try:
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(frames)],
-                           capture_output=True, text=True, timeout=limit_s)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(frames),
+                            "--cpu-out", out_path], capture_output=True, text=True, timeout=limit_s)
         for ln in reversed(r.stdout.strip().splitlines()):
             if ln.startswith("{"):
                 return json.loads(ln)
-        return {"value": None, "unit": "frames/s", "cores": None, "kind": "port", "sample": "failed: " + r.stderr[-200:]}
+        return dict(fail, sample="failed: " + r.stderr[-200:])
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "frames/s", "cores": None, "kind": "port",
-                "sample": f"timed out after {limit_s}s on this host"}
+        return dict(fail, sample=f"timed out after {limit_s}s on this host")
+
+
+def parity_report(gpu_maps, cpu_npz):
+    """Label agreement of the GPU leg with the oracle on the shared frames, up to a permutation of the ids."""
+    from oracle import mean_shift_oracle as O
+    want = np.load(cpu_npz)["final"]
+    n = min(len(want), len(gpu_maps))
+    agree, exact, mism = [], True, []
+    for i in range(n):
+        a, b = gpu_maps[i].astype(np.int64), want[i].astype(np.int64)
+        same = O.labels_equal_up_to_permutation(a, b)
+        # best one-to-one relabelling agreement = pixels on the maximal diagonal of the contingency table
+        ka, kb = int(a.max()) + 1, int(b.max()) + 1
+        table = np.bincount((a * kb + b).ravel(), minlength=ka * kb).reshape(ka, kb)
+        from scipy.optimize import linear_sum_assignment
+        r, c = linear_sum_assignment(-table)
+        ok = int(table[r, c].sum())
+        agree.append(ok / a.size)
+        mism.append(int(a.size - ok))
+        exact = exact and bool(same)
+    return {"frames": n, "label_agreement_min": round(min(agree), 6) if agree else None,
+            "mismatched_pixels": mism, "exact_up_to_permutation": exact if n else None,
+            "against": "oracle/ (torch-CPU restatement pinned to the reference by tests/golden), same frames/seeds/weights"}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# device telemetry for the sustained leg
+# ----------------------------------------------------------------------------------------------------------------
+class SmiSampler(threading.Thread):
+    """Samples sclk / power of GPU `index` through rocm-smi while the sustained loop runs."""
+
+    def __init__(self, index, period=1.0):
+        super().__init__(daemon=True)
+        self.index, self.period, self.samples, self._stop_evt = index, period, [], threading.Event()
+
+    def run(self):
+        while not self._stop_evt.is_set():
+            try:
+                r = subprocess.run(["rocm-smi", "-d", str(self.index), "--showclocks", "--showpower", "--json"],
+                                   capture_output=True, text=True, timeout=10)
+                card = next(iter(json.loads(r.stdout).values()))
+                s = {}
+                for k, v in card.items():
+                    kl = k.lower()
+                    if kl.startswith("sclk clock speed"):
+                        s["sclk_mhz"] = int("".join(ch for ch in str(v) if ch.isdigit()) or 0)
+                    elif "power" in kl and "(w)" in kl:
+                        s["power_w"] = float(v)
+                if s:
+                    self.samples.append(s)
+            except Exception:       # noqa: BLE001 - telemetry is best effort
+                pass
+            self._stop_evt.wait(self.period)
+
+    def stop(self):
+        self._stop_evt.set()
+        self.join(timeout=15)
+        return self.samples
 
 
 def frame_roofline(rois, sec_per_frame):
@@ -102,74 +208,125 @@ def frame_roofline(rois, sec_per_frame):
                     "sampling kernel and Winograd move/execute less than the algorithmic amounts"}
 
 
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one process per GPU)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def stub_frame_fn(h, w):
+    """CPU stand-in for the two-stage frame function (tests of the launcher / sharding / JSON plumbing only; selected
+    by --stub, never on a GPU run): a deterministic label map that consumes the per-frame RNG like the real path."""
+    def fn(g):
+        first = np.random.randint(0, h * w)
+        m = torch.full((h, w), g % 200, dtype=torch.int32)
+        m.view(-1)[first] = 250
+        return m
+    fn.roi_counts = []
+    return fn
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=20, help="frames per GPU (weak scaling)")
+    ap.add_argument("--frames", type=int, default=0,
+                    help="strong scaling: this many frames in total, sharded in contiguous blocks over the GPUs")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cpu-frames", type=int, default=3, help="frames for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=3, help="frames for the CPU baseline + parity (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=4)
+    ap.add_argument("--sustained-seconds", type=float, default=10.0, help="sustained leg at N=1 (0 = skip)")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only > 0:
-        print(json.dumps(cpu_baseline(args.cpu_baseline_only)), flush=True)
-        return
+        print(json.dumps(cpu_baseline(args.cpu_baseline_only, args.cpu_out)), flush=True)
+        return 0
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return relaunch_under_torchrun(args.gpus)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a ROCm device: the product path has no CPU fallback")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    stub = args.stub
+    if stub:
+        device, backend, h, w = torch.device("cpu"), "gloo", 12, 16
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm device: the product path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+        device, backend, h, w = torch.device("cuda", local_rank), "nccl", H, W
     use_dist = world > 1 or os.environ.get("UOC_BENCH_FORCE_DIST") == "1"   # FORCE: exercise the RCCL path on 1 GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        kw = {} if stub else {"device_id": device}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
-    from unseenobjectclustering_amd import _native, networks, runner, synth
-    from unseenobjectclustering_amd.fcn.config import cfg
-    cfg.device = device
+    from unseenobjectclustering_amd import runner
+    sync = (lambda: None) if stub else torch.cuda.synchronize
 
-    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
-    network = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
-    network_crop = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    strong = args.frames > 0
+    total = args.frames if strong else args.steps * world
+    lo, hi = runner.shard_range(total, rank, world)
+    K = (total + world - 1) // world            # frames per GPU = steps
+    if stub:
+        frame_fn = stub_frame_fn(h, w)
+        network = network_crop = samples = None
+    else:
+        from unseenobjectclustering_amd import _native, networks, synth
+        from unseenobjectclustering_amd.fcn.config import cfg
+        cfg.device = device
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+        network = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+        network_crop = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+        host = host_frames(lo, hi)
+        samples = [dict(image_color=torch.from_numpy(a).to(device), depth=torch.from_numpy(b).to(device)) for a, b in host]
+        local_fn = runner.two_stage_frame_fn(samples, network, network_crop)
+        frame_fn = lambda g: local_fn(g - lo)            # global frame index -> this rank's resident sample
+        frame_fn.finish = local_fn.finish
+        frame_fn.roi_counts = local_fn.roi_counts
 
-    K = args.steps
-    distinct = min(K, 8)
-    samples = make_samples(distinct, 10_000 + rank * distinct, device)     # each rank gets its own frames
-    frame_fn = runner.two_stage_frame_fn(samples, network, network_crop)
-
-    def run(nsteps, gather):
-        # frames of this rank: global indices rank*nsteps .. (weak scaling: fixed work per GPU)
-        total = nsteps * world
-        local = lambda i: frame_fn(i - rank * nsteps)
-        local.finish = frame_fn.finish          # clustering status check after the last frame (uoc_ms_check)
-        maps = runner.run_sharded(total, local, H, W, device, rank, world, gather, force_collective=use_dist)
+    def run(nframes_total, gather):
+        maps = runner.run_sharded(nframes_total, frame_fn, h, w, device, rank, world, gather, force_collective=use_dist)
         return maps.cpu()           # label-map block lands on the host inside the timed region
 
-    # setup (never timed, independent of --warmup): one frame so that the native weight copies exist and
-    # the conv autotuner has chosen its tile family / staging variant for every layer shape
-    # ... for EVERY distinct frame: the stage-2 batch size (number of ROIs) differs per frame, and a new batch
-    # size means first-use work (kernel instantiations loading, a tile-height variant's attributes, a tuner
-    # lookup) that must not land in the timed region of a fresh process
-    for i in range(distinct):
-        np.random.seed(runner.frame_rng_seed(i))
-        frame_fn(i)
-    torch.cuda.synchronize()
-    print(f"[bench] rank {rank}: nets built, {distinct} frames resident, warming up", file=sys.stderr, flush=True)
+    if not stub:
+        # setup (never timed, independent of --warmup): the native weight copies, the conv autotuner's choice for
+        # every layer shape, and — because the stage-2 batch size (number of ROIs) differs per frame — the first-use
+        # work of every batch size (kernel instantiations loading, a tile-height variant's attributes, a tuner lookup)
+        for g in range(lo, min(hi, lo + 64)):
+            np.random.seed(runner.frame_rng_seed(g))
+            frame_fn(g)
+        sync()
+        print(f"[bench] rank {rank}: nets built, {hi - lo} frames resident, warming up", file=sys.stderr, flush=True)
     if args.warmup > 0:
-        run(args.warmup, use_dist)
-    print(f"[bench] rank {rank}: warmup done", file=sys.stderr, flush=True)
-    torch.cuda.synchronize()
+        # W frames per GPU through the same code path (collective included).  In strong mode the warm-up shards
+        # W*world frames, which are the first W of rank 0's block only when world == 1 — any frames do.
+        wfn = frame_fn
+        if not stub and world > 1:
+            wfn = lambda g: frame_fn(lo + (g % max(1, hi - lo)))
+            wfn.finish = frame_fn.finish
+        runner.run_sharded(min(args.warmup, K) * world, wfn, h, w, device, rank, world, use_dist,
+                           force_collective=use_dist).cpu()
+    sync()
     if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
-    maps = run(K, use_dist)
-    torch.cuda.synchronize()
+    maps = run(total, use_dist)
+    sync()
     if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -177,34 +334,55 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    objects = float(np.mean([int(m.max()) for m in maps[:K]]))
-    rois = float(np.mean(frame_fn.roi_counts[-K:])) if frame_fn.roi_counts else 0.0
-    pcie = None
-    if rank == 0 and world == 1 and os.environ.get("UOC_BENCH_PCIE") == "1":
-        # informative only (never `value`): the same frames, but uploaded from pageable host memory per frame
-        host = [dict(image_color=s_["image_color"].cpu(), depth=s_["depth"].cpu()) for s_ in samples]
-        fn2 = runner.two_stage_frame_fn(host, network, network_crop)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        runner.run_sharded(K, fn2, H, W, device, 0, 1, False).cpu()
-        torch.cuda.synchronize()
-        pcie = round(K / (time.perf_counter() - t1), 3)
     print(f"[bench] rank {rank}: timed region {dt:.3f}s", file=sys.stderr, flush=True)
+    objects = float(np.mean([int(m.max()) for m in maps[:total]]))
+    counts = frame_fn.roi_counts[-(hi - lo):] if frame_fn.roi_counts else []
+    rois = float(np.mean(counts)) if counts else 0.0
+    solo = rank == 0 and world == 1 and not stub
+
+    pcie = None
+    if solo:
+        # informative only (never `value`): the same frames, uploaded from pageable host memory per frame, as the
+        # reference's test_sample receives them (CPU tensors, test_dataset.py:235-237)
+        hs = [dict(image_color=torch.from_numpy(a), depth=torch.from_numpy(b)) for a, b in host]
+        fn2 = runner.two_stage_frame_fn(hs, network, network_crop)
+        sync()
+        t1 = time.perf_counter()
+        runner.run_sharded(total, fn2, h, w, device, 0, 1, False).cpu()
+        sync()
+        pcie = round(total / (time.perf_counter() - t1), 3)
+
+    sustained = None
+    if solo and args.sustained_seconds > 0:
+        sampler = SmiSampler(local_rank)
+        sampler.start()
+        sync()
+        t1 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t1 < args.sustained_seconds:
+            runner.run_sharded(total, frame_fn, h, w, device, 0, 1, False).cpu()
+            done += total
+        sync()
+        el = time.perf_counter() - t1
+        smp = sampler.stop()
+        sustained = {"seconds": round(el, 2), "frames": done, "frames_per_s": round(done / el, 3),
+                     "sclk_mhz": [s.get("sclk_mhz") for s in smp], "power_w": [s.get("power_w") for s in smp]}
 
     # ---- profiled pass (HIP events around every launch; separate from the timed region) ----
     roof, kernels = None, []
-    if rank == 0 and args.profile_steps > 0:
+    if solo and args.profile_steps > 0:
         _native.prof_enable(True)
-        for i in range(args.profile_steps):
-            np.random.seed(runner.frame_rng_seed(i))
-            frame_fn(i)
-        torch.cuda.synchronize()
+        for g in range(lo, min(hi, lo + args.profile_steps)):
+            np.random.seed(runner.frame_rng_seed(g))
+            frame_fn(g)
+        sync()
+        nprof = min(hi, lo + args.profile_steps) - lo
         rep = _native.prof_report()
         _native.prof_enable(False)
         tot = sum(r["total_ms"] for r in rep) or 1.0
         for r in sorted(rep, key=lambda r: -r["total_ms"]):
             sec = r["total_ms"] / 1e3
-            kernels.append({"kernel": r["kernel"], "launches_per_frame": r["launches"] / args.profile_steps,
+            kernels.append({"kernel": r["kernel"], "launches_per_frame": r["launches"] / nprof,
                             "avg_us": round(1e3 * r["total_ms"] / r["launches"], 2),
                             "gpu_time_share": round(r["total_ms"] / tot, 4),
                             "tflops": round(r["flops"] / sec / 1e12, 2), "gbs": round(r["bytes"] / sec / 1e9, 1)})
@@ -235,27 +413,38 @@ def main():
                     "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2)}
 
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_frames > 0:
-        cpu = cpu_baseline_subprocess(args.cpu_frames)
+    cpu = parity = None
+    if solo and args.cpu_frames > 0:
+        with tempfile.TemporaryDirectory() as td:
+            out_path = os.path.join(td, "cpu_maps.npz")
+            cpu = cpu_baseline_subprocess(min(args.cpu_frames, total), out_path)
+            if os.path.exists(out_path):
+                parity = parity_report(maps.numpy(), out_path)
 
+    if rank == 0 and os.environ.get("UOC_BENCH_DUMP"):     # tests: the label-map block of the timed region
+        np.save(os.environ["UOC_BENCH_DUMP"], maps.numpy())
     if rank == 0:
+        workload = "configs[3]: full two-stage (crop-and-refine) segmentation, 640x480 RGB-D, batch 1"
+        if world > 1 or strong:
+            workload += (f"; configs[4]: {total} frames sharded over {world} GPU(s) in contiguous blocks + "
+                         f"RCCL all_gather of the uint8 label maps" if use_dist else f"; {total} frames on one GPU")
         line = {
             "metric": "frames/sec at 640x480 RGB-D, two-stage clustering",
-            "value": round(K * world / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / K, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[3]: full two-stage (crop-and-refine) segmentation, 640x480 RGB-D, batch 1"
-                                   + ("" if world == 1 else f"; configs[4]: frames sharded over {world} GPUs + RCCL all_gather"),
-                       "frame": "640x480", "seeds": 100, "iters": 10, "crop": 224,
-                       "mean_final_objects": round(objects, 2), "mean_rois": round(rois, 2), "frames_per_gpu": K,
-                       **({"pcie_inclusive_frames_per_s": pcie} if pcie is not None else {})},
-            "roofline": roof, "frame_roofline": frame_roofline(rois, dt / K), "cpu_baseline": cpu, "kernels": kernels,
+            "value": round(total / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / K, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (stub frame function, CPU plumbing test)" if stub else ""),
+            "config": {"workload": workload, "frame": "640x480", "seeds": 100, "iters": 10, "crop": 224,
+                       "total_frames": total, "frames_per_gpu": K, "collective": bool(use_dist),
+                       "mean_final_objects": round(objects, 2), "mean_rois": round(rois, 2)},
+            "pcie_inclusive_frames_per_s": pcie, "sustained": sustained,
+            "roofline": roof, "frame_roofline": frame_roofline(rois, dt / K) if not stub else None,
+            "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -44,6 +44,10 @@ const char *uoc_last_error(void);
 /* Seed selection runs as ONE persistent cooperative launch with X resident on chip when the batch
  * fits the device (default); 0 forces the streaming one-launch-per-step kernel.  Same results. */
 int uoc_ms_set_persistent_fps(int on);
+/* Number of seed-selection calls since process start in which fields that the on-chip kernel should have handled
+ * went to the streaming kernel instead (does not fit on chip / cooperative launch refused).  The two kernels sum the
+ * dot product in different orders; a caller that needs placement-independent results checks that this stays 0. */
+int uoc_ms_fps_fallbacks(void);
 /* The persistent kernel's grid-wide exchange spins with a bound; a block that gives up raises a sticky device
  * flag and the call's outputs are then meaningless.  uoc_ms_check synchronises `stream`, reads and clears the
  * flag: 0, or UOC_ETIMEDOUT.  The host mirrors call it at the points where they synchronise anyway. */

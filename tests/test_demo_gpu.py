@@ -44,10 +44,17 @@ def test_demo_frame_matches_reference(golden_dir, device):
     np.random.seed(3)
     out_label, refined = TD.test_sample(sample, net, net_crop)
     agree, conf = _agreement(out_label.numpy(), g["out_label"])
-    assert agree >= 0.999, agree
-    assert len(np.unique(out_label.numpy())) == len(np.unique(g["out_label"]))
     assert refined is not None
     agree2, _ = _agreement(refined.numpy(), g["refined"])
+    n = out_label.numel()
+    rec = {"stage1_mismatched_pixels": int(round((1 - agree) * n)), "refined_mismatched_pixels": int(round((1 - agree2) * n)),
+           "pixels": n}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    json.dump(rec, open(os.path.join(root, "gpurun_out", "demo_parity.json"), "w"))
+    print("demo frame vs reference golden:", rec)
+    assert agree >= 0.999, agree
+    assert len(np.unique(out_label.numpy())) == len(np.unique(g["out_label"]))
     assert agree2 >= 0.999, agree2
     assert len(np.unique(refined.numpy())) == len(np.unique(g["refined"]))
 

@@ -1,0 +1,64 @@
+"""Parity ON THE HEADLINE WORKLOAD (BASELINE.json configs[3], the frames bench.py times): 640x480 palette frames
+through both calibrated networks and the whole two-stage path on the GPU, against the oracle's test_sample
+(oracle/glue_oracle.py + backbone_oracle.py, the torch-CPU restatement pinned to the reference by tests/golden) on
+the same inputs, RNG seeds and weights.  Reference path: lib/fcn/test_dataset.py:232-267.
+
+north_star's bar: integer label maps equal up to a permutation of the ids.  The measured mismatch counts are
+written to gpurun_out/headline_parity.json so the bound asserted here is a recorded number, not a guess."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import backbone_oracle as BO, glue_oracle as GO, mean_shift_oracle as O
+from unseenobjectclustering_amd import networks, runner, synth
+from unseenobjectclustering_amd.fcn import test_dataset as TD
+from unseenobjectclustering_amd.fcn.config import cfg
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FRAMES = (0, 1)                 # global frame indices of bench.py's set (palette seeds 10000, 10001)
+
+
+def _best_agreement(a, b):
+    """Pixels on which two partitions agree under the best one-to-one relabelling (Hungarian on the contingency table)."""
+    from scipy.optimize import linear_sum_assignment
+    a, b = a.reshape(-1).astype(np.int64), b.reshape(-1).astype(np.int64)
+    kb = int(b.max()) + 1
+    table = np.bincount(a * kb + b, minlength=(int(a.max()) + 1) * kb).reshape(-1, kb)
+    r, c = linear_sum_assignment(-table)
+    return int(table[r, c].sum()), a.size
+
+
+def test_bench_frames_match_oracle(device):
+    cfg.device = device
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    net = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    net_crop = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    cpu_net = lambda img, label, depth: BO.segnet_forward(sd, img, depth)
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    report = []
+    for g in FRAMES:
+        s = 10_000 + g
+        fr = synth.palette_frame(s, 480, 640, 5 + s % 3)
+        img, dep = torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"])
+        want_out, want_ref = GO.test_sample(img, dep, cpu_net, cpu_net, np.random.RandomState(runner.frame_rng_seed(g)))
+        np.random.seed(runner.frame_rng_seed(g))
+        got_out, got_ref = TD.test_sample(dict(image_color=img, depth=dep), net, net_crop)
+        rois = len(np.unique(want_out.numpy())) - 1
+        assert rois >= 6, "the headline frames must exercise stage 2 with >= 6 ROIs"
+        assert (want_ref is None) == (got_ref is None)
+        ok1, n = _best_agreement(got_out.numpy(), want_out.numpy())
+        ok2, _ = _best_agreement(got_ref.numpy(), want_ref.numpy())
+        report.append({"frame": g, "rois": rois, "stage1_mismatched_pixels": n - ok1, "refined_mismatched_pixels": n - ok2,
+                       "stage1_exact_up_to_permutation": bool(O.labels_equal_up_to_permutation(got_out.numpy(), want_out.numpy())),
+                       "refined_exact_up_to_permutation": bool(O.labels_equal_up_to_permutation(got_ref.numpy(), want_ref.numpy())),
+                       "objects": int(want_ref.max())})
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(report, open(os.path.join(ROOT, "gpurun_out", "headline_parity.json"), "w"), indent=1)
+    print(json.dumps(report))
+    for r in report:
+        assert r["stage1_exact_up_to_permutation"], r
+        assert r["refined_exact_up_to_permutation"], r

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/uoc_hip.h"
 
 namespace uoc {
@@ -33,6 +35,34 @@ void set_error(const char *fmt, ...);
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Per-device one-time state.  hipFuncSetAttribute (dynamic LDS above 64 KB) applies to the CURRENT device's copy of a
+// kernel, and a process may drive several GPUs (the reference wraps its nets in DataParallel), so "done once" flags
+// are kept per device ordinal, not per process.
+constexpr int kMaxDevices = 64;
+static inline int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+  return d;
+}
+struct DeviceOnce {
+  std::atomic<unsigned long long> bits{0};
+  bool done() const { return (bits.load(std::memory_order_acquire) >> current_device()) & 1ull; }
+  void mark() { bits.fetch_or(1ull << current_device(), std::memory_order_release); }
+};
+// Compute-unit count of the current device (cached per device).
+static inline int device_num_cu() {
+  static std::atomic<int> cached[kMaxDevices];
+  const int d = current_device();
+  int v = cached[d].load(std::memory_order_relaxed);
+  if (v == 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, d) != hipSuccess) return 0;
+    v = prop.multiProcessorCount;
+    cached[d].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
 
 // ---- wave64 cross-lane helpers (DPP; one VALU op each, no LDS) -------------------------
 // Row = 16 lanes.  quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror = 0x141,

@@ -16,6 +16,7 @@ struct ConvParams {
   int G, B, H, W, Cin, Ho, Wo, Cout;
   int KH, KW, stride, dil, pad, relu;
   int stem;           // 1: 7x7 s2 p3 conv over NHWC4 input, K-chunk = one kernel row
+  int tune = 1;       // 0: never autotune for this call (generic C entry: the tuner re-launches into `out` and syncs)
 };
 
 int launch_conv(const ConvParams &p, hipStream_t st);

@@ -16,6 +16,8 @@
 // With weights as the MFMA "A" operand, each lane ends up holding 4 CONSECUTIVE output channels
 // of one pixel, so the epilogue is float4 loads/stores in NHWC.
 #include "conv.h"
+
+#include <mutex>
 #include "prof.h"
 
 #include <stdlib.h>
@@ -480,11 +482,11 @@ static int launch_glds(const ConvParams &p, hipStream_t st, int kc) {
   ProfScope prof(kc, st, flops, bytes);
   const int mtiles = (M + BM - 1) / BM, ntiles = p.Cout / BN;
   const size_t lds = (size_t)3 * (BM + BN) * BK * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_glds_kernel<BM, BN, WAVES_M, WAVES_N, STEM, VARIANT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark();
   }
   const int total = mtiles * ntiles * p.G;
   hipLaunchKernelGGL((conv_glds_kernel<BM, BN, WAVES_M, WAVES_N, STEM, VARIANT>), dim3(((total + 7) / 8) * 8),
@@ -517,11 +519,11 @@ static int launch_cfg(const ConvParams &p, hipStream_t st, int kc) {
   ProfScope prof(kc, st, flops, bytes);
   const int mtiles = (M + BM - 1) / BM, ntiles = p.Cout / BN;
   const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, STEM, VARIANT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark();
   }
   const int total = mtiles * ntiles * p.G;
   hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, STEM, VARIANT>), dim3(((total + 7) / 8) * 8),
@@ -675,7 +677,10 @@ static void tune_cache_append(const TuneEntry &e) {
   fclose(f);
 }
 
+static std::mutex g_tune_mutex;   // the tuner's table is process-wide (choices are per layer shape, valid on every
+                                  // identical device) and may be reached from several host threads
 static Choice choose(const ConvParams &p, hipStream_t st, int glds_default) {
+  std::lock_guard<std::mutex> lock(g_tune_mutex);
   static int autotune = -1, pin_cfg = -2, pin_glds = -2;
   if (autotune < 0) {
     const char *e = getenv("UOC_CONV_AUTOTUNE");
@@ -699,7 +704,7 @@ static Choice choose(const ConvParams &p, hipStream_t st, int glds_default) {
     // same layer, other batch: reuse if the tile is still legal, never re-tune mid-stream
     return g_tuned[nearest].choice;
   }
-  if (g_ntuned >= 256) return stat;
+  if (g_ntuned >= 256 || !p.tune) return stat;
   const bool prof_was = g_prof_enabled;
   g_prof_enabled = false;
   hipEvent_t e0, e1;

@@ -145,11 +145,11 @@ int uoc_eval_pair_stats(const int32_t *d_pred, const int32_t *d_gt, int H, int W
   int blocks = (n + 1023) / 1024;
   if (blocks > 64) blocks = 64;
   const size_t lds = (size_t)EL * EL * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&eval_stats_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark();
   }
   hipLaunchKernelGGL(eval_stats_kernel, dim3(blocks), dim3(1024), lds, st, d_pred, d_gt, H, W, d_tables->cont,
                      d_tables->bnd_pred, d_tables->bnd_gt, pk_pred, pk_gt, &d_tables->bad_label);

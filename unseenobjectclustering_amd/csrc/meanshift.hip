@@ -78,6 +78,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
   int cur;
   if (step == 0) {
     cur = first_index[b];
+    if (cur < 0 || cur >= n) cur = 0;  // the host mirrors validate; never read outside X
   } else {
     ArgMax best = {-INFINITY, INT_MAX};
     for (int i = tid; i < nblk; i += FPS_THREADS) {
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
     for (int w = 1; w < FPS_THREADS / 64; ++w)
       if (better(red[w], best)) best = red[w];
     cur = best.idx;
+    if (cur < 0 || cur >= n) cur = 0;  // all-NaN distances leave idx = INT_MAX (the on-chip kernel clamps too)
     __syncthreads();
   }
   if (blockIdx.x == 0) {
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
   for (int j = 0; j < FPP_SLOTS; ++j) dm[j] = 0.f;
 
   int cur = __builtin_amdgcn_readfirstlane(first_index[item]);
+  if (cur < 0 || cur >= n) cur = 0;  // the host mirrors validate; never read outside X
   if (blk == 0) {
     if (tid == 0) indices[0] = cur;
     if (tid < 16) *reinterpret_cast<float4 *>(seeds + 4 * tid) = *reinterpret_cast<const float4 *>(X + (size_t)cur * C + 4 * tid);
@@ -884,15 +887,11 @@ static int fps_blocks(int n) {
   return nblk;
 }
 
-static int g_num_cu = 0;
 static int g_fps_persistent = -1;  // -1: read UOC_FPS_PERSISTENT on first use
+static std::atomic<int> g_fps_fallbacks{0};
 static int fps_persistent_plan(int batch, int n, int *bpi, int *nslots) {
-  if (g_num_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    g_num_cu = prop.multiProcessorCount;
-  }
+  const int g_num_cu = device_num_cu();  // of the CURRENT device
+  if (g_num_cu <= 0) return 0;
   if (g_fps_persistent < 0) {
     const char *e = getenv("UOC_FPS_PERSISTENT");
     g_fps_persistent = e ? atoi(e) : 1;
@@ -930,11 +929,11 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
     UOC_HIP_CHECK(hipMemsetAsync(gran, 0, gbytes, st));  // tag 0 = "not published": re-initialised every call
     UOC_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int), st));
     const size_t lds = (size_t)FPP_LS * (C / 4) * FPP_THREADS * sizeof(float4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (!attr_set.done()) {
       UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_persistent_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
+      attr_set.mark();
     }
     const float *Xc = X + (size_t)done * n * C;
     const int32_t *fc = first + done;
@@ -955,6 +954,13 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
     done += sub;
   }
   if (done >= batch) return UOC_OK;
+  if (g_fps_persistent != 0 && w.nh == 1 && m >= 2) {
+    // Observable fallback: the streaming kernel sums the 64-d dot product in another order, so a near-tied argmax may
+    // pick another pixel than the on-chip kernel would have.  Count it and say so once.
+    if (g_fps_fallbacks.fetch_add(1) == 0)
+      fprintf(stderr, "[uoc] farthest-point sampling: %d of %d field(s) of n=%d ran on the streaming kernel (the on-chip "
+              "kernel does not fit / is not co-resident on this device); see uoc_ms_fps_fallbacks()\n", batch - done, batch, n);
+  }
   return run_select_seeds_streaming(X + (size_t)done * w.nh * n * C, batch - done, n, m, first + done,
                                     seeds + (size_t)done * w.nh * m * C, indices + (size_t)done * m, w, st);
 }
@@ -984,11 +990,11 @@ static void launch_hc(const float *X, int batch, int n, float *Z, int m, float k
   const size_t zbytes = (size_t)NH * ST * 16 * ZP * sizeof(float);
   const size_t rbytes = (size_t)2 * ST * 4 * 64 * sizeof(f32x4);
   const size_t lds = zbytes > rbytes ? zbytes : rbytes;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done() && lds > 64 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hc_iter_kernel<ST, NH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_set.mark();
   }
   for (int it = 0; it < iters; ++it) {
     {
@@ -1035,11 +1041,11 @@ static void launch_assign(const float *X, int batch, int n, const float *Z, cons
   const int maxb = ((n + 15) / 16 + 3) / 4;
   if (nblk > maxb) nblk = maxb;
   const size_t lds = (size_t)NH * ST * 16 * ZP * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && lds > 48 * 1024) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done() && lds > 48 * 1024) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&assign_kernel<ST, NH>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_set.mark();
   }
   ProfScope prof(KC_ASSIGN, st, 2.0 * batch * m * (double)n * C * NH, 4.0 * batch * ((double)n * C * NH + n));
   hipLaunchKernelGGL((assign_kernel<ST, NH>), dim3(nblk, batch), dim3(HC_THREADS), lds, st, X, n, Z, seed_labels, m,
@@ -1082,11 +1088,11 @@ static int run_seed_cc(const float *Z, int batch, int m, float eps, int *seed_la
   ProfScope prof(KC_SEED_CC, st, 0.0, 4.0 * batch * m * C * nh);
   const size_t lds = (size_t)NLAB * (nh * C + 1) * sizeof(float);
   if (nh == 2) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce attr_set;
+    if (!attr_set.done()) {
       UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&seed_cc_kernel<2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
+      attr_set.mark();
     }
     hipLaunchKernelGGL(seed_cc_kernel<2>, dim3(batch), dim3(64), lds, st, Z, m, eps, seed_labels, num_unique);
   } else {
@@ -1106,6 +1112,8 @@ int uoc_ms_set_persistent_fps(int on) {
   g_fps_persistent = on ? 1 : 0;
   return UOC_OK;
 }
+
+int uoc_ms_fps_fallbacks(void) { return g_fps_fallbacks.load(); }
 
 int uoc_ms_check(void *stream) {
   hipStream_t st = (hipStream_t)stream;

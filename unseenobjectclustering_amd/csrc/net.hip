@@ -377,7 +377,9 @@ int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, co
                     int B, int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu,
                     void *stream) {
   UOC_REQUIRE(K == 1 || K == 3, "K=%d (only 1 or 3)", K);
+  UOC_REQUIRE(d_res == nullptr || d_res != d_out, "conv2d: the residual must not alias the output");
   ConvParams p;
+  p.tune = 0;   // static tile choice: no timing launches into the caller's buffers, no host-side sync
   p.in = d_in;
   p.w = d_w;
   p.bias = d_bias;

@@ -423,11 +423,11 @@ static int launch_wino_gemm(const ConvParams &p, const float *U, const float *V,
   const int mtiles = (geo.NT + BM - 1) / BM, ntiles = p.Cout / WBN;
   const size_t lds = (size_t)NSTG * 2 * (BM + WBN) * WBK * sizeof(float);
   static_assert((size_t)NSTG * 2 * (BM + WBN) * WBK * sizeof(float) <= 160 * 1024, "LDS ring too large");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (!attr_set.done()) {
     UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&wino_gemm_kernel<TMT, NSTG, VARIANT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    attr_set.mark();
   }
   const int total = mtiles * ntiles * p.G;
   hipLaunchKernelGGL((wino_gemm_kernel<TMT, NSTG, VARIANT>), dim3(((total + 7) / 8) * 8), dim3(512), lds, st,

@@ -55,6 +55,16 @@ def _pixel_major(features: torch.Tensor) -> torch.Tensor:
     return x.reshape(B, h * w, C)
 
 
+def _detach_keep_planes(features: torch.Tensor) -> torch.Tensor:
+    """features.detach() like the reference (:247), keeping the kernel-layout buffer the 128-d 'cat' output of
+    SEGNET.forward carries as `_uoc_planes` (detach() returns a new tensor object without Python attributes)."""
+    planes = getattr(features, "_uoc_planes", None)
+    features = features.detach()
+    if planes is not None:
+        features._uoc_planes = planes
+    return features
+
+
 def _cluster_device(features: torch.Tensor, num_seeds: int = 100):
     """Device-resident clustering of every batch item: int32 labels [B, h*w], indices [B, m]."""
     require_supported()
@@ -254,7 +264,7 @@ def _run_frame(sample, network, network_crop, depth_threshold, return_device=Fal
     label = sample["label"].to(dev) if "label" in sample else None
     B, _, H, W = image.shape
 
-    features = network(image, label, depth).detach()
+    features = _detach_keep_planes(network(image, label, depth))          # :247
     labels, _ = _cluster_device(features, num_seeds=100)                 # [B, H*W] int32 on the device
 
     # depth filter (:250-252) fused with the ROI table build for item 0; other items filter only
@@ -275,7 +285,7 @@ def _run_frame(sample, network, network_crop, depth_threshold, return_device=Fal
         LAST_FRAME_STATS["rois"] = K
         if K > 0:
             rgb_crop, mask_crop, depth_crop = _crop(image, depth, labels[0], table, K, H, W, dev)
-            features_crop = network_crop(rgb_crop, mask_crop, depth_crop)
+            features_crop = _detach_keep_planes(network_crop(rgb_crop, mask_crop, depth_crop))     # :259
             labels_crop, _ = _cluster_device(features_crop)              # K fields, one launch set
             refined, _ = _match(labels_crop, mask_crop, depth_crop, table, K, H, W, dev)
             out_label_refined = refined.view(1, H, W)

@@ -34,17 +34,39 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
                 force_collective: bool = False) -> Optional[torch.Tensor]:
     """Runs frame_fn(global_index) -> [H,W] integer label map (on `device`) for this rank's block
     and all-gathers the uint8 blocks.  Returns [num_frames, H, W] uint8 on `device` (every rank),
-    or only the local block when gather=False / world == 1."""
+    or only the local block when gather=False / world == 1.
+
+    Error handling: a rank whose block failed (an exception in frame_fn, the clustering status check, or a
+    label id that does not fit uint8) must not leave the others waiting in the collective, so every rank
+    first all-reduces an error flag and ALL ranks raise when any rank failed."""
     per = (num_frames + world - 1) // world
     lo, hi = shard_range(num_frames, rank, world)
     block = torch.zeros((per, height, width), dtype=torch.uint8, device=device)
-    for i in range(lo, hi):
-        np.random.seed(frame_rng_seed(i))
-        block[i - lo] = frame_fn(i).to(torch.uint8)
-    if hasattr(frame_fn, "finish") and device.type == "cuda":
-        frame_fn.finish(device)
-    if (world == 1 and not force_collective) or not gather:
+    collective = gather and (world > 1 or force_collective)
+    error = None
+    try:
+        top = torch.zeros((), dtype=torch.int64, device=device)
+        for i in range(lo, hi):
+            np.random.seed(frame_rng_seed(i))
+            m = frame_fn(i)
+            top = torch.maximum(top, m.max().to(torch.int64))
+            block[i - lo] = m.to(torch.uint8)
+        if hasattr(frame_fn, "finish") and device.type == "cuda":
+            frame_fn.finish(device)
+        if hi > lo and int(top) > 255:       # one sync per block, after the last frame
+            raise ValueError(f"label id {int(top)} does not fit the uint8 label-map block")
+    except Exception as e:       # noqa: BLE001 - re-raised below, on every rank
+        if not collective:
+            raise
+        error = e
+    if not collective:
         return block[:hi - lo]
+    flag = torch.tensor([1 if error is not None else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()) != 0:
+        if error is not None:
+            raise error
+        raise RuntimeError("another rank failed in its frame block; aborting before the all_gather")
     full = torch.empty((world * per, height, width), dtype=torch.uint8, device=device)
     dist.all_gather_into_tensor(full, block)
     return full[:num_frames]

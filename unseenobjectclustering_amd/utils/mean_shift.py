@@ -46,6 +46,16 @@ def _require_cosine(metric):
         raise NotImplementedError("only metric='cosine' is implemented on gfx950")
 
 
+def _first_indices(first_index, B: int, n: int) -> torch.Tensor:
+    """The B first-seed indices as an int32 host tensor, validated: the kernels read row X[first] directly."""
+    first = np.asarray(first_index, dtype=np.int64).reshape(-1)
+    if first.shape[0] != B:
+        raise ValueError(f"first_index: expected {B} indices, got {first.shape[0]}")
+    if first.size and (first.min() < 0 or first.max() >= n):
+        raise ValueError(f"first_index out of range [0, {n}): {first.tolist()}")
+    return torch.from_numpy(first.astype(np.int32))
+
+
 def to_planes(X: torch.Tensor) -> torch.Tensor:
     """[B, n, 128] pixel-major rows -> the [B, 2, n, 64] plane layout of the 128-d kernels (a copy)."""
     B, n, d = X.shape
@@ -70,7 +80,7 @@ def cluster_batch(X: torch.Tensor, first_index, kappa: float = 20.0, num_seeds: 
         epsilon = 2 * cfg.TRAIN.EMBEDDING_ALPHA
     dev = X.device
     L = _native.lib()
-    first = torch.as_tensor(np.asarray(first_index, dtype=np.int32).reshape(B)).to(dev)
+    first = _first_indices(first_index, B, n).to(dev)
     labels = torch.empty((B, n), dtype=torch.int32, device=dev)
     indices = torch.empty((B, num_seeds), dtype=torch.int32, device=dev)
     Z = torch.empty((B, num_seeds, EMBED_DIM), dtype=torch.float32, device=dev)
@@ -95,7 +105,7 @@ def _cluster_batch_wide(X, first_index, kappa, num_seeds, max_iters, epsilon, re
         epsilon = 2 * cfg.TRAIN.EMBEDDING_ALPHA
     dev = X.device
     L = _native.lib()
-    first = torch.as_tensor(np.asarray(first_index, dtype=np.int32).reshape(B)).to(dev)
+    first = _first_indices(first_index, B, n).to(dev)
     labels = torch.empty((B, n), dtype=torch.int32, device=dev)
     indices = torch.empty((B, num_seeds), dtype=torch.int32, device=dev)
     Z = torch.empty((B, H2, num_seeds, EMBED_DIM), dtype=torch.float32, device=dev)
