@@ -100,7 +100,10 @@ def cpu_baseline(frames, out_path):
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, ncpu))
+    # The oracle is many small torch ops; beyond ~64 threads the intra-op pool only adds synchronisation cost (with
+    # all 256+ hardware threads of the bench box a frame took minutes instead of seconds), so the thread count is
+    # capped at 64 and both numbers are reported: `cores` = threads used, `host_cores` = what the box has.
+    torch.set_num_threads(max(1, min(ncpu, 64)))
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
     net = lambda img, label, depth: BO.segnet_forward(sd, img, depth)
     inputs = host_frames(0, frames)
