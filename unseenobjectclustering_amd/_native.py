@@ -130,6 +130,13 @@ def stream_ptr(device=None):
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def stream_key(device):
+    """(device type, index, current HIP stream handle): the key of every per-stream scratch cache, so that frames in
+    flight on different streams never share a workspace."""
+    import torch
+    return (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream))
+
+
 def prof_enable(on: bool):
     lib().uoc_prof_reset()
     lib().uoc_prof_enable(1 if on else 0)

@@ -17,6 +17,9 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
+#include <utility>
+
 namespace uoc {
 
 constexpr int C = UOC_EMBED_DIM;  // 64 channels
@@ -550,6 +553,257 @@ __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__rest
   }
 }
 
+// -------------------------------------------------------------------------------------------
+// The same iteration, register-resident formulation (64-d fields; default).
+//
+// What the disassembly of hc_iter_kernel shows (round 2): hipcc re-orders the source's 1:1 interleave into runs of
+// 4-16 DEPENDENT MFMAs on one accumulator, issues every seed-fragment ds_read right before its first use
+// (s_waitcnt lgkmcnt straight after the read: the LDS latency is exposed 14 times per pixel tile) and expands expf()
+// into 14 VALU instructions, 5 of them range guards that cannot trigger for |kappa S| <= 20.  So here
+//   * ONE wave per SIMD owns up to 512 registers: the seed fragments of all ST tiles (16 VGPRs each) stay in registers
+//     for the whole kernel — no LDS access in the main loop at all, nothing to wait for but the pixel prefetch;
+//   * the instruction order is pinned with sched_barrier(0) fences between k-steps: S-chain MFMA, accumulate MFMA
+//     (another accumulator), then one slice of the exp() arithmetic of the previous seed tile in their shadow;
+//   * exp() is the same arithmetic as the library's expf (x*log2e split hi/lo, v_exp, ldexp), bit-identical for the
+//     in-range arguments of this kernel, without the guards: 9 VALU.
+// -------------------------------------------------------------------------------------------
+// exp(kappa * s) as seven single-instruction steps, so that the kernel can place them one by one (elements round-robin)
+// and never issues two dependent VALU in a row.  fp32 MFMA and VALU share the SIMD's fp32 lanes on gfx950
+// (scripts/mfma_shadow.hip: MFMA + K v_fma = 35.5 + 2K cycles, a v_exp 8 more, from one wave or from two), so every
+// VALU instruction here is paid for in matrix-pipe time: x = kappa*s rounded like the reference's elementwise
+// multiply; t = fl(x log2e); v_exp(t) (1 ulp over the whole range, |t| <= 29 here); the rounding error of t,
+// e = (x*log2e_hi - t) + x*log2e_lo, re-enters as 2^e = 1 + e ln2.  Within ~1.5 ulp of exp(x); the library expf spends
+// four more instructions (rndne / sub / cvt / ldexp) on a range reduction v_exp does not need and five on guards that
+// cannot trigger for |x| <= 20.
+struct ExpState {
+  float x, t, e, p;
+};
+#pragma clang fp contract(off)
+template <int STEP>
+__device__ __forceinline__ void exp_step(ExpState &e, float s, float kappa, float &w) {
+  if (STEP == 0) e.x = kappa * s;
+  if (STEP == 1) e.t = e.x * 0x1.715476p+0f;                        // log2(e) hi (0x3fb8aa3b)
+  if (STEP == 2) e.e = __builtin_fmaf(e.x, 0x1.715476p+0f, -e.t);
+  if (STEP == 3) e.e = __builtin_fmaf(e.x, 0x1.4ae0bep-26f, e.e);   // log2(e) lo (0x32a5705f)
+  if (STEP == 4) e.p = __builtin_amdgcn_exp2f(e.t);
+  if (STEP == 5) e.e = e.e * 0x1.62e43p-1f;                         // ln 2
+  if (STEP == 6) w = __builtin_fmaf(e.p, e.e, e.p);
+}
+#pragma clang fp contract(fast)
+constexpr int EXP_STEPS = 7;
+
+
+// One pixel tile (16 pixels) against all ST seed tiles.  3-stage pipeline over the seed tiles, fully unrolled; step i:
+//   1. the S-chain of tile i: 16 DEPENDENT MFMAs on one accumulator, strictly back to back — consecutive accumulation
+//      into the same registers runs at the matrix pipe's full 32-cycle rate, but any instruction between two of them
+//      (another MFMA, a VALU) costs 4-9 cycles per MFMA (scripts/mfma_mix.hip: S A S A 36.0, S v A v 40.5, against
+//      32.0 for 16 S then 16 A);
+//   2. the 16 independent accumulate MFMAs of tile i-2 (four accumulators in rotation), each followed by two or
+//      three single VALU steps of the exp() of tile i-1, elements round-robin so no VALU waits on the one before it
+//      (a VALU behind an independent MFMA costs ~1.7 cycles of issue, same microbenchmark: 35.3).
+// sched_barrier(0) after every slot keeps hipcc from regrouping.
+// ABL (timing ablations, dev only; results are wrong for ABL != 0): 1 = no exp arithmetic, 4 = S chains only,
+// 5 = accumulate MFMAs only.
+template <int ST, int ABL, int I>
+__device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&zb)[ST][4],
+                                         f32x4 (&acc)[ST][4], f32x4 (&Sv)[ST + 2], float (&wv)[ST + 2][4],
+                                         ExpState (&es)[4], float kappa) {
+  // Sv / wv carry two spare rows so that the (never executed) I-1 / I-2 references of the first steps stay in range
+  constexpr bool do_s = I < ST && ABL != 5, do_a = I >= 2 && ABL != 4, do_e = I >= 1 && I - 1 < ST;
+  constexpr int IS = I < ST ? I : 0, IE = I >= 1 ? I - 1 : 0, IA = I >= 2 ? I - 2 : 0;
+  if (do_s) {
+    Sv[IS] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int v = k >> 2, e = k & 3;
+      Sv[IS] = mfma4(f4c(xa[v], e), f4c(zb[IS][v], e), Sv[IS]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  constexpr int nops = do_e ? 4 * EXP_STEPS : 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (do_a) {
+      const int r = k >> 2, ct = k & 3;
+      acc[IA][ct] = mfma4(wv[IA][r], f4c(xb[r], ct), acc[IA][ct]);
+    }
+    // the VALU steps that belong behind this slot, in 4 clusters per seed tile (behind MFMAs 3, 7, 11, 15): every
+    // MFMA -> VALU switch costs ~2.7 cycles on top of the VALU's own 2 (scripts/mfma_shadow.hip)
+    const int c = k >> 2, o0 = (k & 3) == 3 ? c * nops / 4 : 0, o1 = (k & 3) == 3 ? (c + 1) * nops / 4 : 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {           // 28 / 4 = 7 steps per cluster; fixed trip count so it unrolls
+      const int o = o0 + j;
+      if (o >= o1) continue;
+      const int step = o >> 2, r = o & 3;   // step-major, element-minor: consecutive ops are independent
+      if (ABL == 1 || ABL == 5) {
+        if (step == 0) wv[IE][r] = ABL == 5 ? f4c(xa[r], I & 3) : kappa * Sv[IE][r];
+      } else if (ABL == 4) {
+        if (step == 0) acc[IE][r] += Sv[IE];
+      } else {
+        switch (step) {
+          case 0: exp_step<0>(es[r], Sv[IE][r], kappa, wv[IE][r]); break;
+          case 1: exp_step<1>(es[r], 0.f, kappa, wv[IE][r]); break;
+          case 2: exp_step<2>(es[r], 0.f, kappa, wv[IE][r]); break;
+          case 3: exp_step<3>(es[r], 0.f, kappa, wv[IE][r]); break;
+          case 4: exp_step<4>(es[r], 0.f, kappa, wv[IE][r]); break;
+          case 5: exp_step<5>(es[r], 0.f, kappa, wv[IE][r]); break;
+          default: exp_step<6>(es[r], 0.f, kappa, wv[IE][r]); break;
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int ST, int ABL, int... Is>
+__device__ __forceinline__ void hcr_tile_steps(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&zb)[ST][4],
+                                               f32x4 (&acc)[ST][4], float kappa, std::integer_sequence<int, Is...>) {
+  f32x4 Sv[ST + 2];
+  float wv[ST + 2][4];
+  ExpState es[4];
+  (hcr_step<ST, ABL, Is>(xa, xb, zb, acc, Sv, wv, es, kappa), ...);
+}
+
+template <int ST, int ABL>
+__device__ __forceinline__ void hcr_tile(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&zb)[ST][4],
+                                         f32x4 (&acc)[ST][4], float kappa) {
+  hcr_tile_steps<ST, ABL>(xa, xb, zb, acc, kappa, std::make_integer_sequence<int, ST + 2>{});
+}
+
+// The work of one wave: seed tiles [T0, T0 + NT) against the wave's pixel tiles; leaves its 4*NT accumulator
+// registers in LDS for the block's reduction.
+template <int NT, int ABL>
+__device__ __forceinline__ void hcr_run(const float *__restrict__ X, int n, const float *__restrict__ Z, int m, int T0,
+                                        float kappa, int tile, int stride, f32x4 *red_wave, int lane) {
+  const int t = lane & 15, q = lane >> 4;
+  // seed fragments: zb[i][v] = Z[seed 16(T0+i)+t][16v+4q .. +3]  (B operand of S^T = X Z^T), zero rows beyond m.
+  // Unconditional loads from a clamped row + a select later: a predicated load would get its own branch and its own
+  // s_waitcnt vmcnt(0), i.e. NT serialised memory latencies in the prologue.
+  float4 zb[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      zb[i][v] = *reinterpret_cast<const float4 *>(Z + (size_t)min(16 * (T0 + i) + t, m - 1) * C + 16 * v + 4 * q);
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int s = 0; s < NT; ++s)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[s][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ntile = (n + 15) >> 4;
+  // Pixel tiles: branch-free loads (clamped row index).  A clamped xa row only produces a finite S / W for a pixel
+  // whose xb row is zeroed, so out-of-range pixels contribute exactly 0; xb is zeroed only in the (rare) partial tile.
+  auto load_tile = [&](int tl, float4(&a)[4], float4(&bb)[4]) {
+    const int base = min(tl, ntile - 1) * 16;
+    const int pa = min(base + t, n - 1);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[v] = *reinterpret_cast<const float4 *>(X + (size_t)pa * C + 16 * v + 4 * q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int pb = base + 4 * q + r;
+      bb[r] = *reinterpret_cast<const float4 *>(X + (size_t)min(pb, n - 1) * C + 4 * t);
+    }
+  };
+  // applied when the tile becomes the current one (a select on freshly loaded data would force a wait at the load)
+  auto mask_tile = [&](int tl, float4(&bb)[4]) {
+    const int base = min(tl, ntile - 1) * 16;
+    if (base + 16 > n) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (base + 4 * q + r >= n) bb[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  float4 xa[4], xb[4];
+  load_tile(tile, xa, xb);
+  mask_tile(tile, xb);
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      if (16 * (T0 + i) + t >= m) zb[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // The loads of the wave's NEXT tile are issued before the current tile's MFMAs and first read after them.
+  // hipcc undoes a plain `xa = na` double buffer (it coalesces the copy, rotates the loop and ends up with
+  // load-then-wait at the top of every tile, ~0.8 us exposed per tile) and sinks the loads of a two-body ping-pong
+  // loop into the second body — so the hand-over is 32 opaque v_mov and a sched_barrier keeps the loads above the
+  // first MFMA.
+  for (; tile < ntile; tile += stride) {
+    float4 na[4], nb[4];
+    load_tile(tile + stride, na, nb);
+    __builtin_amdgcn_sched_barrier(0);
+    hcr_tile<NT, ABL>(xa, xb, zb, acc, kappa);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                   : "=&v"(xa[v].x), "=&v"(xa[v].y), "=&v"(xa[v].z), "=&v"(xa[v].w)
+                   : "v"(na[v].x), "v"(na[v].y), "v"(na[v].z), "v"(na[v].w));
+      asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                   : "=&v"(xb[v].x), "=&v"(xb[v].y), "=&v"(xb[v].z), "=&v"(xb[v].w)
+                   : "v"(nb[v].x), "v"(nb[v].y), "v"(nb[v].z), "v"(nb[v].w));
+    }
+    mask_tile(tile + stride, xb);
+  }
+#pragma unroll
+  for (int s = 0; s < NT; ++s)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) red_wave[(s * 4 + ct) * 64 + lane] = acc[s][ct];
+}
+
+// Block = 8 waves = TWO per SIMD, because a wave cannot overlap its own VALU work with its own MFMAs: with one wave
+// per SIMD every one of the ~340 VALU instructions of a pixel tile (exp arithmetic, accumulator reads, the hand-over)
+// cost 8 cycles of matrix-pipe time (measured: 9 880 cycles per tile against 224 x 32 = 7 168), whereas the VALU of one
+// wave runs beside the MFMAs of the other (separate pipes, MI355X_MICROARCH.md).  Two waves of 324 registers do not fit
+// a SIMD, so the SEEDS are split: waves 0-3 own seed tiles [0, ceil(ST/2)), waves 4-7 the rest; waves w and w+4 (same
+// SIMD under the round-robin wave placement) walk the same pixel tiles, each loading them itself (the second read is
+// an L1/L2 hit).  Every wave: <= 64 seed-fragment + 64 accumulator + 64 pixel registers.
+constexpr int HCR_THREADS = 512;
+constexpr int HCR_WPG = 4;  // waves per seed group
+
+template <int ST, int ABL = 0>
+__global__ __launch_bounds__(HCR_THREADS) void hc_iter_reg_kernel(const float *__restrict__ X, int n,
+                                                                  const float *__restrict__ Z, int m, float kappa,
+                                                                  float *__restrict__ partial) {
+  constexpr int STA = (ST + 1) / 2, STB = ST / 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // only the cross-wave reduction of the epilogue
+  const int b = blockIdx.y;
+  const int nblk = gridDim.x;
+  X += (size_t)b * n * C;
+  Z += (size_t)b * m * C;
+  partial += ((size_t)b * nblk + blockIdx.x) * (ST * 16) * C;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave / HCR_WPG, wg = wave % HCR_WPG;
+  const int t = lane & 15, q = lane >> 4;
+  const int stride = nblk * HCR_WPG;
+  const int tile = blockIdx.x * HCR_WPG + wg;
+  f32x4 *red = reinterpret_cast<f32x4 *>(smem);  // [8 waves][STA*4][64] f32x4
+  f32x4 *red_wave = red + (size_t)wave * STA * 4 * 64;
+  if (grp == 0) {
+    hcr_run<STA, ABL>(X, n, Z, m, 0, kappa, tile, stride, red_wave, lane);
+  } else if (STB > 0) {
+    hcr_run<(STB > 0 ? STB : 1), ABL>(X, n, Z, m, STA, kappa, tile, stride, red_wave, lane);
+  }
+  __syncthreads();
+  // ---- reduction: seed tile s of group g is summed over the group's four waves in the fixed order
+  // ((w0 + w1) + (w2 + w3)); the 8 waves share the ST tiles round-robin ----
+  for (int s = wave; s < ST; s += HCR_THREADS / 64) {
+    const int g = s < STA ? 0 : 1, sl = s - g * STA;
+    const f32x4 *base = red + (size_t)g * HCR_WPG * STA * 4 * 64;
+    f32x4 o[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const f32x4 a0 = base[((0 * STA + sl) * 4 + ct) * 64 + lane], a1 = base[((1 * STA + sl) * 4 + ct) * 64 + lane];
+      const f32x4 a2 = base[((2 * STA + sl) * 4 + ct) * 64 + lane], a3 = base[((3 * STA + sl) * 4 + ct) * 64 + lane];
+      o[ct] = (a0 + a1) + (a2 + a3);
+    }
+    // lane (t,q) reg r holds newZ[seed 16s+4q+r][channel 4t+ct]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<float4 *>(partial + (size_t)(16 * s + 4 * q + r) * C + 4 * t) =
+          make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+  }
+}
+
 // Z[seed] = normalize(sum_blk partial[blk][seed])  (F.normalize, eps 1e-12; mean_shift.py:107)
 // partial [b][blk][NH][rows][64] -> Z [b][NH][m][64], the norm runs over all NH * 64 channels.
 // One block per seed: 16 lanes x float4 cover a 256-byte row, so a wave reads the rows of 4 blocks per load and
@@ -826,17 +1080,29 @@ struct MsWorkspace {
   size_t total;
 };
 
-static int hc_blocks(int batch, int n) {
+// UOC_HC_VARIANT: 1 (default) = register-resident kernel, one wave per SIMD (64-d fields); 0 = LDS-fragment kernel
+static int hc_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char *e = getenv("UOC_HC_VARIANT");
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
+static int hc_blocks(int batch, int n, int nh = 1, bool lds_kernel = false) {
   const int ntile = (n + 15) / 16;
   // two 4-wave blocks per CU (253 registers => 2 waves/SIMD, 57 KB LDS each); more blocks only add
   // prologue (Z -> LDS) / epilogue (partial reduce + 28 KB store) work and partial traffic
   static int target = 0;
   if (!target) {
     const char *e = getenv("UOC_HC_BLOCKS");
-    target = e ? atoi(e) : 512;
-    if (target < 1) target = 512;
+    target = e ? atoi(e) : 0;
+    if (target < 1) target = 0;
   }
-  int nblk = target / (batch > 0 ? batch : 1);
+  // register-resident kernel: one 4-wave block per CU; LDS-fragment kernel: two
+  const int tgt = target ? target : ((!lds_kernel && nh == 1 && hc_variant() == 1 && device_num_cu() > 0) ? device_num_cu() : 512);
+  int nblk = tgt / (batch > 0 ? batch : 1);
   if (nblk < 8) nblk = 8;
   const int maxb = (ntile + 3) / 4;
   if (nblk > maxb) nblk = maxb;
@@ -853,7 +1119,7 @@ static MsWorkspace carve(void *base, int batch, int n, int nh = 1) {
     off += align_up(bytes, 256);
     return p;
   };
-  w.hc_nblk = hc_blocks(batch, n);
+  w.hc_nblk = hc_blocks(batch, n, nh);
   w.dmin = (float *)take((size_t)batch * n * sizeof(float));
   w.part[0] = (ArgMax *)take((size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax));
   w.part[1] = (ArgMax *)take((size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax));
@@ -913,6 +1179,30 @@ static int fps_persistent_plan(int batch, int n, int *bpi, int *nslots) {
 static int run_select_seeds_streaming(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
                                       int32_t *indices, const MsWorkspace &w, hipStream_t st);
 
+// One event per device that orders the persistent sampling kernels of all streams (see run_select_seeds).
+struct FpsChain {
+  std::mutex mu;
+  hipEvent_t ev[kMaxDevices] = {};
+  hipEvent_t event() {
+    const int d = current_device();
+    if (!ev[d] && hipEventCreateWithFlags(&ev[d], hipEventDisableTiming) != hipSuccess) ev[d] = nullptr;
+    return ev[d];
+  }
+};
+static FpsChain &fps_chain() {
+  static FpsChain c;
+  return c;
+}
+// UOC_FPS_COOP=0: plain launch of the persistent grid (co-residency then rests on the plan + the event chain alone)
+static bool fps_cooperative() {
+  static int coop = -1;
+  if (coop < 0) {
+    const char *e = getenv("UOC_FPS_COOP");
+    coop = e ? atoi(e) : 1;
+  }
+  return coop != 0;
+}
+
 static int run_select_seeds(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
                             int32_t *indices, const MsWorkspace &w, hipStream_t st) {
   // Persistent path: as many items per cooperative launch as stay co-resident; a larger batch
@@ -928,11 +1218,14 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
     if (gbytes > (size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax)) break;
     UOC_HIP_CHECK(hipMemsetAsync(gran, 0, gbytes, st));  // tag 0 = "not published": re-initialised every call
     UOC_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int), st));
-    const size_t lds = (size_t)FPP_LS * (C / 4) * FPP_THREADS * sizeof(float4);
+    // the LDS pixel slot is only touched when a lane owns more than FPP_RS pixels; without it the kernel needs no
+    // dynamic LDS at all and can share a CU with another stream's convolution blocks (two frames in flight)
+    const size_t lds = nslots > FPP_RS ? (size_t)FPP_LS * (C / 4) * FPP_THREADS * sizeof(float4) : 0;
     static DeviceOnce attr_set;
     if (!attr_set.done()) {
       UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_persistent_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)((size_t)FPP_LS * (C / 4) * FPP_THREADS * sizeof(float4))));
       attr_set.mark();
     }
     const float *Xc = X + (size_t)done * n * C;
@@ -943,9 +1236,23 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
                     (void *)&sc, (void *)&ic, (void *)&gran, (void *)&status};
     hipError_t e;
     {
-      ProfScope prof(KC_FPS_STEP, st, 2.0 * sub * (double)n * C * (m - 1), 4.0 * sub * (double)n * C);
-      e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&fps_persistent_kernel), dim3(sub * bpi),
-                                     dim3(FPP_THREADS), args, (unsigned)lds, st);
+      // Persistent grids from different streams (two frames in flight) must not be partially resident at the same
+      // time — each would spin for peers the other one keeps off the chip.  A per-device event chain runs them one
+      // after the other; everything else on the two streams still overlaps.
+      FpsChain &chain = fps_chain();
+      std::lock_guard<std::mutex> lock(chain.mu);
+      hipEvent_t ev = chain.event();
+      if (ev) UOC_HIP_CHECK(hipStreamWaitEvent(st, ev, 0));
+      {
+        ProfScope prof(KC_FPS_STEP, st, 2.0 * sub * (double)n * C * (m - 1), 4.0 * sub * (double)n * C);
+        if (fps_cooperative())
+          e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&fps_persistent_kernel), dim3(sub * bpi),
+                                         dim3(FPP_THREADS), args, (unsigned)lds, st);
+        else
+          e = hipLaunchKernel(reinterpret_cast<const void *>(&fps_persistent_kernel), dim3(sub * bpi), dim3(FPP_THREADS),
+                              args, lds, st);
+      }
+      if (e == hipSuccess && ev) UOC_HIP_CHECK(hipEventRecord(ev, st));
     }
     if (e != hipSuccess) {
       (void)hipGetLastError();  // not co-resident on this device: the rest goes to the streaming path
@@ -996,13 +1303,42 @@ static void launch_hc(const float *X, int batch, int n, float *Z, int m, float k
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set.mark();
   }
+  const bool reg = NH == 1 && hc_variant() == 1;
+  const size_t lds_reg = (size_t)8 * ((ST + 1) / 2) * 4 * 64 * sizeof(f32x4);
+  if constexpr (NH == 1) {
+    static DeviceOnce attr_reg;
+    if (reg && !attr_reg.done() && lds_reg > 64 * 1024) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hc_iter_reg_kernel<ST>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+      attr_reg.mark();
+    }
+  }
   for (int it = 0; it < iters; ++it) {
     {
       // NH = 2 recomputes S for each half of the accumulators: (2 + 1) / 2 of the algorithmic flops per half
       ProfScope prof(KC_HC_ITER, st, 4.0 * batch * m * (double)n * C * NH,
                      4.0 * batch * ((double)n * C * NH + 2.0 * m * C * NH));
-      hipLaunchKernelGGL((hc_iter_kernel<ST, NH>), dim3(w.hc_nblk, batch, NH), dim3(HC_THREADS), lds, st, X, n, Z, m,
-                         kappa, w.hc_partial);
+      if constexpr (NH == 1) {
+        if (reg) {
+          static int abl = -1;
+          if (abl < 0) {
+            const char *e = getenv("UOC_HC_ABLATE");  // dev only: timing ablations of the ST = 7 kernel
+            abl = e ? atoi(e) : 0;
+          }
+          const dim3 g(w.hc_nblk, batch), bdim(HCR_THREADS);
+          auto go = [&](auto kern, bool set_attr) {
+            if (set_attr) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+            hipLaunchKernelGGL(kern, g, bdim, lds_reg, st, X, n, Z, m, kappa, w.hc_partial);
+          };
+          if (ST == 7 && abl == 1) go(hc_iter_reg_kernel<ST, (ST == 7 ? 1 : 0)>, true);
+          else if (ST == 7 && abl == 4) go(hc_iter_reg_kernel<ST, (ST == 7 ? 4 : 0)>, true);
+          else if (ST == 7 && abl == 5) go(hc_iter_reg_kernel<ST, (ST == 7 ? 5 : 0)>, true);
+          else go(hc_iter_reg_kernel<ST, 0>, false);
+        }
+      }
+      if (!reg)
+        hipLaunchKernelGGL((hc_iter_kernel<ST, NH>), dim3(w.hc_nblk, batch, NH), dim3(HC_THREADS), lds, st, X, n, Z, m,
+                           kappa, w.hc_partial);
     }
     ProfScope prof(KC_HC_FINALIZE, st, 0.0, 4.0 * batch * w.hc_nblk * NH * ST * 16.0 * C);
     hipLaunchKernelGGL(hc_finalize_kernel<NH>, dim3(m, batch), dim3(256), 0, st, w.hc_partial, w.hc_nblk, ST * 16, m, Z);
@@ -1037,7 +1373,7 @@ static int run_hill_climb(const float *X, int batch, int n, float *Z, int m, flo
 template <int ST, int NH>
 static void launch_assign(const float *X, int batch, int n, const float *Z, const int *seed_labels, int m,
                           int *labels, int *closest, const MsWorkspace &w, hipStream_t st) {
-  int nblk = hc_blocks(batch, n) * 2;
+  int nblk = hc_blocks(batch, n, 1, true) * 2;
   const int maxb = ((n + 15) / 16 + 3) / 4;
   if (nblk > maxb) nblk = maxb;
   const size_t lds = (size_t)NH * ST * 16 * ZP * sizeof(float);

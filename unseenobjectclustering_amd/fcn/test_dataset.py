@@ -40,7 +40,7 @@ def _device():
 
 
 def _ws(dev):
-    key = (dev.type, dev.index)
+    key = _native.stream_key(dev)      # one scratch buffer per stream: two frames in flight must not share it
     if key not in _roi_ws:
         _roi_ws[key] = torch.empty(_native.lib().uoc_roi_workspace_bytes() + 256, dtype=torch.uint8, device=dev)
     return _roi_ws[key]
@@ -65,8 +65,10 @@ def _detach_keep_planes(features: torch.Tensor) -> torch.Tensor:
     return features
 
 
-def _cluster_device(features: torch.Tensor, num_seeds: int = 100):
-    """Device-resident clustering of every batch item: int32 labels [B, h*w], indices [B, m]."""
+def _cluster_device(features: torch.Tensor, num_seeds: int = 100, rng=None):
+    """Device-resident clustering of every batch item: int32 labels [B, h*w], indices [B, m].
+    `rng`: where the first-seed draws come from — the global NumPy RNG like the reference (mean_shift.py:155), or a
+    per-frame np.random.RandomState when several frames are in flight and must not interleave their draws."""
     require_supported()
     if not features.is_cuda:
         raise _native.NativeError("features must be on a ROCm device (no CPU fallback)")
@@ -78,7 +80,8 @@ def _cluster_device(features: torch.Tensor, num_seeds: int = 100):
         if X.shape[-1] == 128:
             X = to_planes(X)
     B, n = X.shape[0], X.shape[-2]
-    firsts = [np.random.randint(0, n) for _ in range(B)]   # mean_shift.py:155, one draw per field, in order
+    draw = (rng if rng is not None else np.random).randint
+    firsts = [draw(0, n) for _ in range(B)]                # mean_shift.py:155, one draw per field, in order
     return cluster_batch(X, firsts, KAPPA, num_seeds, MAX_ITERS, 2 * cfg.TRAIN.EMBEDDING_ALPHA)
 
 
@@ -185,8 +188,33 @@ def _order_and_map(keep: np.ndarray, sort_key: torch.Tensor):
     return np.asarray(order, dtype=np.int32), mapping
 
 
-def _match(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev):
-    """labels_crop_i32 [K, S*S] int32 (device) -> refined int32 [H*W] (device), keep table (host)."""
+class _HostMirror:
+    """Pinned host buffers of one frame slot: the two small device->host reads of a frame (ROI table; keep table + mean
+    depths) and the host->device paint plan go through them as asynchronous copies guarded by an event, so the host
+    can queue another frame's work on another stream while a read is in flight."""
+
+    def __init__(self):
+        n = MAX_LABELS * MAX_LABELS + MAX_LABELS
+        self.table = torch.empty(_native.ROI_TABLE_BYTES, dtype=torch.uint8).pin_memory()
+        self.stats = torch.empty(n, dtype=torch.int32).pin_memory()
+        self.plan = torch.empty(n, dtype=torch.int32).pin_memory()
+        self.table_ready = torch.cuda.Event()
+        self.stats_ready = torch.cuda.Event()
+
+
+_mirrors = {}
+
+
+def _mirror(dev) -> _HostMirror:
+    key = _native.stream_key(dev)
+    if key not in _mirrors:
+        _mirrors[key] = _HostMirror()
+    return _mirrors[key]
+
+
+def _match_stats(labels_crop_i32, mask_crops, depth_crops, K, dev):
+    """Overlap / mean-depth statistics of the K clustered crops (:118-148), one launch over all ROIs.
+    Returns the device buffer [K*128 keep flags | K mean depths]."""
     S = cfg.TRAIN.SYN_CROP_SIZE
     L = _native.lib()
     ws = _ws(dev)
@@ -199,22 +227,42 @@ def _match(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev):
                                    _native.ptr(keep), _native.ptr(meanz), _native.ptr(ws), ws.numel(),
                                    _native.stream_ptr(dev))
     _native.check(rc, "uoc_roi_match_stats")
-    stats_h = stats.cpu()
+    return stats
+
+
+def _paste(labels_crop_i32, table_dev, table_host, stats_h, has_depth, K, H, W, dev, plan_host=None):
+    """Host ordering of the ROIs (:129-151) from the statistics read back, then one paste launch (:156-177)."""
+    S = cfg.TRAIN.SYN_CROP_SIZE
+    L = _native.lib()
     keep_h = stats_h[:K * MAX_LABELS].view(K, MAX_LABELS).numpy()
-    if meanz is not None:
-        sort_key = stats_h[K * MAX_LABELS:].view(torch.float32)
+    if has_depth:
+        sort_key = stats_h[K * MAX_LABELS:K * MAX_LABELS + K].view(torch.float32)
     else:       # :138-146 roi_size = (y_max - y_min + 1) * (x_max - x_min + 1), float32 like the reference's rois
-        box = torch.tensor(np.ctypeslib.as_array(_read_table(table).box)[:K].astype(np.float32))
+        box = torch.tensor(np.ctypeslib.as_array(table_host.box)[:K].astype(np.float32))
         sort_key = (box[:, 3] - box[:, 1] + 1) * (box[:, 2] - box[:, 0] + 1)
     order, mapping = _order_and_map(keep_h, sort_key)
-    plan = torch.from_numpy(np.concatenate([order.reshape(-1), mapping.reshape(-1)]).astype(np.int32)).to(dev)
+    flat = np.concatenate([order.reshape(-1), mapping.reshape(-1)]).astype(np.int32)
+    if plan_host is not None:
+        plan_host[:flat.size].copy_(torch.from_numpy(flat))
+        plan = plan_host[:flat.size].to(dev, non_blocking=True)
+    else:
+        plan = torch.from_numpy(flat).to(dev)
     order_d, map_d = plan[:K], plan[K:]
     refined = torch.empty((H * W,), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        rc = L.uoc_roi_paste(_native.ptr(labels_crop_i32), _native.ptr(table), _native.ptr(map_d), _native.ptr(order_d),
+        rc = L.uoc_roi_paste(_native.ptr(labels_crop_i32), _native.ptr(table_dev), _native.ptr(map_d), _native.ptr(order_d),
                              K, S, H, W, _native.ptr(refined), _native.stream_ptr(dev))
     _native.check(rc, "uoc_roi_paste")
-    return refined, keep
+    return refined
+
+
+def _match(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev):
+    """labels_crop_i32 [K, S*S] int32 (device) -> refined int32 [H*W] (device), keep table (device)."""
+    stats = _match_stats(labels_crop_i32, mask_crops, depth_crops, K, dev)
+    stats_h = stats.cpu()
+    table_host = _read_table(table) if depth_crops is None else None
+    refined = _paste(labels_crop_i32, table, table_host, stats_h, depth_crops is not None, K, H, W, dev)
+    return refined, stats[:K * MAX_LABELS].view(K, MAX_LABELS)
 
 
 def match_label_crop(initial_masks, labels_crop, out_label_crop, rois, depth_crop):
@@ -248,55 +296,113 @@ def test_sample(sample, network, network_crop):
     return _run_frame(sample, network, network_crop, DEPTH_FILTER)
 
 
+class FrameJob:
+    """One frame on its way through the two-stage path, cut at the two points where the host needs a small result
+    from the device (the number of ROIs; which crop clusters to keep and in which order to paint the ROIs):
+
+        stage1  embed, cluster, depth filter + ROI table          -> async D2H of the table
+        stage2  (needs K) crop, embed + cluster the K crops, match statistics -> async D2H of the statistics
+        stage3  (needs the statistics) host ordering, paste
+
+    `_run_frame` runs the three stages back to back; runner.run_pipelined keeps several jobs in flight, each on its
+    own stream, so that one frame's latency-bound phases (farthest-point sampling, seed components, glue, the reads)
+    overlap another frame's convolutions.  Results do not depend on the interleaving: every job draws its first seeds
+    from its own `rng`."""
+
+    def __init__(self, sample, network, network_crop, depth_threshold, rng=None):
+        self.sample, self.network, self.network_crop = sample, network, network_crop
+        self.depth_threshold, self.rng = depth_threshold, rng
+        self.K = 0
+        self.labels = self.refined = None
+
+    def stage1(self):
+        require_supported()
+        dev = self.dev = _device()
+        sample = self.sample
+        if "image_u8" in sample:  # raw uint8 / uint16 sample: input preparation runs on the device (io.prepare_on_device)
+            from ..io import prepare_on_device
+            sample = dict(sample, **prepare_on_device(sample, dev))
+        pin = lambda t: t.to(dev, non_blocking=True) if (not t.is_cuda and t.is_pinned()) else t.to(dev)
+        self.image = image = pin(sample["image_color"]).float().contiguous()
+        self.depth = depth = pin(sample["depth"]).float().contiguous() if uses_depth() else None     # :236-239
+        if depth is None:
+            self.depth_threshold = None                                                           # :250 `if depth is not None`
+        thr = self.depth_threshold
+        label = sample["label"].to(dev) if "label" in sample else None
+        B, _, H, W = image.shape
+        self.B, self.H, self.W = B, H, W
+
+        features = _detach_keep_planes(self.network(image, label, depth))          # :247
+        labels, _ = _cluster_device(features, num_seeds=100, rng=self.rng)         # [B, H*W] int32 on the device
+        self.labels = labels
+
+        # depth filter (:250-252) fused with the ROI table build for item 0; other items filter only
+        zptr = ctypes.c_void_p(depth.data_ptr() + 2 * H * W * 4) if thr is not None else ctypes.c_void_p(0)
+        self.table = _build_rois(labels[0], zptr, H, W, dev, thr if thr is not None else 0.0)
+        if B > 1 and thr is not None:
+            L = _native.lib()
+            ws = _ws(dev)
+            z1 = ctypes.c_void_p(depth.data_ptr() + (3 * H * W + 2 * H * W) * 4)
+            with torch.cuda.device(dev):
+                _native.check(L.uoc_filter_labels_depth(_native.ptr(labels[1:]), z1, 3 * H * W, B - 1, H, W, float(thr),
+                                                        _native.ptr(ws), ws.numel(), _native.stream_ptr(dev)),
+                              "uoc_filter_labels_depth")
+        if self.network_crop is not None:
+            self.host = _mirror(dev)
+            self.host.table.copy_(self.table, non_blocking=True)
+            self.host.table_ready.record(torch.cuda.current_stream(dev))
+
+    def stage2(self):
+        if self.network_crop is None:
+            return
+        dev, H, W = self.dev, self.H, self.W
+        self.host.table_ready.synchronize()
+        self.table_host = _native.RoiTable.from_buffer_copy(self.host.table.numpy().tobytes())
+        K = self.K = int(self.table_host.K)
+        if K == 0:
+            return
+        rgb_crop, mask_crop, depth_crop = _crop(self.image, self.depth, self.labels[0], self.table, K, H, W, dev)
+        features_crop = _detach_keep_planes(self.network_crop(rgb_crop, mask_crop, depth_crop))     # :259
+        self.labels_crop, _ = _cluster_device(features_crop, rng=self.rng)      # K fields, one launch set
+        self.has_depth = depth_crop is not None
+        stats = _match_stats(self.labels_crop, mask_crop, depth_crop, K, dev)
+        self.host.stats[:stats.numel()].copy_(stats, non_blocking=True)
+        self.host.stats_ready.record(torch.cuda.current_stream(dev))
+
+    def stage3(self):
+        if self.network_crop is None or self.K == 0:
+            return
+        dev, H, W, B, K = self.dev, self.H, self.W, self.B, self.K
+        self.host.stats_ready.synchronize()
+        refined = _paste(self.labels_crop, self.table, self.table_host, self.host.stats, self.has_depth, K, H, W, dev,
+                         plan_host=self.host.plan)
+        out = refined.view(1, H, W)
+        if B > 1:    # match_label_crop returns zeros_like(initial_masks) with only item 0 painted (:153,:176-177)
+            full = torch.zeros((B, H, W), dtype=refined.dtype, device=dev)
+            full[0] = out[0]
+            out = full
+        self.refined = out
+        self.labels_crop = self.image = self.depth = None      # release the big intermediates
+
+    def result_device(self):
+        """(labels [B,H,W] int32, refined [B,H,W] int32 or None), on the device."""
+        return self.labels.view(self.B, self.H, self.W), self.refined
+
+
 def _run_frame(sample, network, network_crop, depth_threshold, return_device=False):
     """Per-frame body shared by test_sample (:247-261) and test_segnet (:288-321).
     depth_threshold None = no depth-coverage filter.  return_device=True keeps the int32 label
     maps on the device ([B,H,W], [1,H,W] or None) for the frame-parallel runner."""
-    require_supported()
-    dev = _device()
-    if "image_u8" in sample:      # raw uint8 / uint16 sample: input preparation runs on the device (io.prepare_on_device)
-        from ..io import prepare_on_device
-        sample = dict(sample, **prepare_on_device(sample, dev))
-    image = sample["image_color"].to(dev).float().contiguous()
-    depth = sample["depth"].to(dev).float().contiguous() if uses_depth() else None       # :236-239
-    if depth is None:
-        depth_threshold = None                                                            # :250 `if depth is not None`
-    label = sample["label"].to(dev) if "label" in sample else None
-    B, _, H, W = image.shape
-
-    features = _detach_keep_planes(network(image, label, depth))          # :247
-    labels, _ = _cluster_device(features, num_seeds=100)                 # [B, H*W] int32 on the device
-
-    # depth filter (:250-252) fused with the ROI table build for item 0; other items filter only
-    zptr = ctypes.c_void_p(depth.data_ptr() + 2 * H * W * 4) if depth_threshold is not None else ctypes.c_void_p(0)
-    table = _build_rois(labels[0], zptr, H, W, dev, depth_threshold if depth_threshold is not None else 0.0)
-    if B > 1 and depth_threshold is not None:
-        L = _native.lib()
-        ws = _ws(dev)
-        z1 = ctypes.c_void_p(depth.data_ptr() + (3 * H * W + 2 * H * W) * 4)
-        with torch.cuda.device(dev):
-            _native.check(L.uoc_filter_labels_depth(_native.ptr(labels[1:]), z1, 3 * H * W, B - 1, H, W, float(depth_threshold),
-                                                    _native.ptr(ws), ws.numel(), _native.stream_ptr(dev)),
-                          "uoc_filter_labels_depth")
-
-    out_label_refined = None
-    if network_crop is not None:
-        K = int(_read_table(table).K)
-        LAST_FRAME_STATS["rois"] = K
-        if K > 0:
-            rgb_crop, mask_crop, depth_crop = _crop(image, depth, labels[0], table, K, H, W, dev)
-            features_crop = _detach_keep_planes(network_crop(rgb_crop, mask_crop, depth_crop))     # :259
-            labels_crop, _ = _cluster_device(features_crop)              # K fields, one launch set
-            refined, _ = _match(labels_crop, mask_crop, depth_crop, table, K, H, W, dev)
-            out_label_refined = refined.view(1, H, W)
-            if B > 1:    # match_label_crop returns zeros_like(initial_masks) with only item 0 painted (:153,:176-177)
-                full = torch.zeros((B, H, W), dtype=refined.dtype, device=dev)
-                full[0] = out_label_refined[0]
-                out_label_refined = full
+    job = FrameJob(sample, network, network_crop, depth_threshold)
+    job.stage1()
+    job.stage2()
+    job.stage3()
+    LAST_FRAME_STATS["rois"] = job.K
+    labels, out_label_refined = job.result_device()
     if return_device:
-        return labels.view(B, H, W), out_label_refined
-    _check_clustering(dev)
-    out_label = labels.view(B, H, W).float().cpu()
+        return labels, out_label_refined
+    _check_clustering(job.dev)
+    out_label = labels.float().cpu()
     if out_label_refined is not None:
         out_label_refined = out_label_refined.float().cpu()
     return out_label, out_label_refined

@@ -167,7 +167,7 @@ _net_ws = {}
 
 
 def _net_workspace(device, nbytes):
-    key = (device.type, device.index)
+    key = _native.stream_key(device)      # one activation arena per stream (frames in flight do not share it)
     ws = _net_ws.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)

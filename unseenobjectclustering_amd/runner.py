@@ -9,6 +9,8 @@ Sharding-independent results: the NumPy RNG that picks the first mean-shift seed
 """
 from __future__ import annotations
 
+import os
+from collections import deque
 from typing import Callable, Optional
 
 import numpy as np
@@ -31,26 +33,35 @@ def frame_rng_seed(frame_index: int) -> int:
 
 def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height: int, width: int,
                 device: torch.device, rank: int = 0, world: int = 1, gather: bool = True,
-                force_collective: bool = False) -> Optional[torch.Tensor]:
+                force_collective: bool = False, inflight: Optional[int] = None) -> Optional[torch.Tensor]:
     """Runs frame_fn(global_index) -> [H,W] integer label map (on `device`) for this rank's block
     and all-gathers the uint8 blocks.  Returns [num_frames, H, W] uint8 on `device` (every rank),
     or only the local block when gather=False / world == 1.
 
     Error handling: a rank whose block failed (an exception in frame_fn, the clustering status check, or a
     label id that does not fit uint8) must not leave the others waiting in the collective, so every rank
-    first all-reduces an error flag and ALL ranks raise when any rank failed."""
+    first all-reduces an error flag and ALL ranks raise when any rank failed.
+
+    `inflight` (default: $UOC_FRAMES_IN_FLIGHT or 2): when frame_fn offers `make_job` (two_stage_frame_fn does), that
+    many frames are kept in flight on this GPU, each on its own stream (_run_block_pipelined); 1 = one frame at a
+    time on the current stream.  The label maps are the same either way."""
     per = (num_frames + world - 1) // world
     lo, hi = shard_range(num_frames, rank, world)
     block = torch.zeros((per, height, width), dtype=torch.uint8, device=device)
     collective = gather and (world > 1 or force_collective)
     error = None
+    if inflight is None:
+        inflight = int(os.environ.get("UOC_FRAMES_IN_FLIGHT", "2"))
     try:
-        top = torch.zeros((), dtype=torch.int64, device=device)
-        for i in range(lo, hi):
-            np.random.seed(frame_rng_seed(i))
-            m = frame_fn(i)
-            top = torch.maximum(top, m.max().to(torch.int64))
-            block[i - lo] = m.to(torch.uint8)
+        if inflight > 1 and device.type == "cuda" and hasattr(frame_fn, "make_job"):
+            top = _run_block_pipelined(frame_fn, lo, hi, block, device, inflight)
+        else:
+            top = torch.zeros((), dtype=torch.int64, device=device)
+            for i in range(lo, hi):
+                np.random.seed(frame_rng_seed(i))
+                m = frame_fn(i)
+                top = torch.maximum(top, m.max().to(torch.int64))
+                block[i - lo] = m.to(torch.uint8)
         if hasattr(frame_fn, "finish") and device.type == "cuda":
             frame_fn.finish(device)
         if hi > lo and int(top) > 255:       # one sync per block, after the last frame
@@ -72,15 +83,75 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     return full[:num_frames]
 
 
-def two_stage_frame_fn(samples, network, network_crop):
+def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device: torch.device, depth: int):
+    """Frames lo..hi-1 of this rank with `depth` of them in flight, one stream per slot (fcn.test_dataset.FrameJob).
+
+    A frame has two points where the host needs a few bytes from the device (ROI count; crop keep table + ROI order).
+    With one frame at a time the matrix pipes idle through those reads and through the latency-bound kernels around
+    them (farthest-point sampling 2 x 0.5 ms, seed components, glue).  Here the host queues frame i+1's embedding +
+    clustering on another stream BEFORE it waits for frame i's reads, so the GPU always has a second frame's kernels
+    to fill the gaps.  One host thread; per-stream workspaces; per-frame RandomState, so the label maps do not depend
+    on the interleaving.  Returns the largest label id seen (device scalar)."""
+    main = torch.cuda.current_stream(device)
+    streams = _slot_streams(device, depth)
+    for st in streams:
+        st.wait_stream(main)                      # inputs / weights were produced on the caller's stream
+    tops = [torch.zeros((), dtype=torch.int64, device=device) for _ in streams]
+    pending = deque()
+    nxt = lo
+
+    def issue_stage1(i):
+        slot = (i - lo) % depth
+        with torch.cuda.stream(streams[slot]):
+            job = frame_fn.make_job(i)
+            job.stage1()
+        return i, slot, job
+
+    while nxt < hi or pending:
+        while nxt < hi and len(pending) < depth:
+            pending.append(issue_stage1(nxt))
+            nxt += 1
+        i, slot, job = pending.popleft()
+        with torch.cuda.stream(streams[slot]):
+            job.stage2()                          # blocks on this frame's ROI table only
+            job.stage3()                          # blocks on this frame's statistics; the other slots keep the GPU busy
+            labels, refined = job.result_device()
+            m = (refined if refined is not None else labels)[0]
+            tops[slot] = torch.maximum(tops[slot], m.max().to(torch.int64))
+            block[i - lo] = m.to(torch.uint8)
+        frame_fn.roi_counts.append(job.K)
+    for st in streams:
+        main.wait_stream(st)
+    return torch.stack(tops).max()
+
+
+_streams = {}
+
+
+def _slot_streams(device, depth):
+    key = (device.type, device.index)
+    pool = _streams.setdefault(key, [])
+    while len(pool) < depth:
+        pool.append(torch.cuda.Stream(device))
+    return pool[:depth]
+
+
+def two_stage_frame_fn(samples, network, network_crop, first_index: int = 0):
     """frame_fn over pre-uploaded samples: final label map = refined map if stage 2 produced one,
-    else the stage-1 map (what test_segnet stores as labels_refined, test_dataset.py:324-327)."""
-    from .fcn.test_dataset import _run_frame, _check_clustering, DEPTH_FILTER, LAST_FRAME_STATS
+    else the stage-1 map (what test_segnet stores as labels_refined, test_dataset.py:324-327).
+    Global frame i reads samples[(i - first_index) % len(samples)] (a rank passes the start of its block)."""
+    from .fcn.test_dataset import _run_frame, _check_clustering, DEPTH_FILTER, LAST_FRAME_STATS, FrameJob
 
     def fn(i: int) -> torch.Tensor:
-        out, refined = _run_frame(samples[i % len(samples)], network, network_crop, DEPTH_FILTER, return_device=True)
+        out, refined = _run_frame(samples[(i - first_index) % len(samples)], network, network_crop, DEPTH_FILTER, return_device=True)
         fn.roi_counts.append(LAST_FRAME_STATS["rois"])
         return (refined if refined is not None else out)[0]
+
+    def make_job(i: int):
+        """The same frame as a FrameJob for the pipelined runner, with its own RNG seeded from the global index."""
+        return FrameJob(samples[(i - first_index) % len(samples)], network, network_crop, DEPTH_FILTER,
+                        rng=np.random.RandomState(frame_rng_seed(i)))
+    fn.make_job = make_job
     fn.roi_counts = []          # stage-1 ROIs per processed frame (the bench derives the algorithmic work from it)
     # every frame checks the clustering status once after stage 1 (a sticky device flag, so a stage-2 failure
     # surfaces at the next frame); fn.finish() is the check after the last frame

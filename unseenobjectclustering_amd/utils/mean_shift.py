@@ -23,7 +23,7 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
-    key = (device.type, device.index)
+    key = _native.stream_key(device)      # one scratch buffer per stream (frames in flight do not share it)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
@@ -53,7 +53,7 @@ def _first_indices(first_index, B: int, n: int) -> torch.Tensor:
         raise ValueError(f"first_index: expected {B} indices, got {first.shape[0]}")
     if first.size and (first.min() < 0 or first.max() >= n):
         raise ValueError(f"first_index out of range [0, {n}): {first.tolist()}")
-    return torch.from_numpy(first.astype(np.int32))
+    return torch.from_numpy(first.astype(np.int32)).pin_memory()     # pinned: the upload never blocks on the stream
 
 
 def to_planes(X: torch.Tensor) -> torch.Tensor:
@@ -80,7 +80,7 @@ def cluster_batch(X: torch.Tensor, first_index, kappa: float = 20.0, num_seeds: 
         epsilon = 2 * cfg.TRAIN.EMBEDDING_ALPHA
     dev = X.device
     L = _native.lib()
-    first = _first_indices(first_index, B, n).to(dev)
+    first = _first_indices(first_index, B, n).to(dev, non_blocking=True)
     labels = torch.empty((B, n), dtype=torch.int32, device=dev)
     indices = torch.empty((B, num_seeds), dtype=torch.int32, device=dev)
     Z = torch.empty((B, num_seeds, EMBED_DIM), dtype=torch.float32, device=dev)
@@ -105,7 +105,7 @@ def _cluster_batch_wide(X, first_index, kappa, num_seeds, max_iters, epsilon, re
         epsilon = 2 * cfg.TRAIN.EMBEDDING_ALPHA
     dev = X.device
     L = _native.lib()
-    first = _first_indices(first_index, B, n).to(dev)
+    first = _first_indices(first_index, B, n).to(dev, non_blocking=True)
     labels = torch.empty((B, n), dtype=torch.int32, device=dev)
     indices = torch.empty((B, num_seeds), dtype=torch.int32, device=dev)
     Z = torch.empty((B, H2, num_seeds, EMBED_DIM), dtype=torch.float32, device=dev)
