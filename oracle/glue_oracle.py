@@ -138,3 +138,32 @@ def test_sample(image: torch.Tensor, depth: torch.Tensor, network, network_crop,
             labels_c = clustering_features(f2, [rng.randint(0, n2) for _ in range(f2.shape[0])])
             refined, _ = match_label_crop(out_label, labels_c, mask_c, rois, depth_c)
     return out_label, refined
+
+
+def test_segnet(test_loader, network, network_crop, rng: np.random.RandomState):
+    """test_dataset.py:271-381, the per-frame body only (the metrics are restated in evaluation_oracle): cluster,
+    depth-coverage filter with the per-dataset threshold (:299-305: 0.5 for 'ocid', 0.8 for 'osd', none otherwise),
+    refine.  Returns [(prediction [H,W] float32, prediction_refined [H,W] float32)], what the reference stores in
+    the .mat files (:334-340; without a refined map the stage-1 prediction is stored twice, :324-327)."""
+    name = test_loader.dataset.name
+    out = []
+    for sample in test_loader:
+        image, depth = sample["image_color"], sample.get("depth")
+        features = network(image, sample["label"], depth)
+        n = features.shape[2] * features.shape[3]
+        out_label = clustering_features(features, [rng.randint(0, n) for _ in range(features.shape[0])])
+        if "ocid" in name and depth is not None:
+            out_label = filter_labels_depth(out_label, depth, 0.5)
+        if "osd" in name and depth is not None:
+            out_label = filter_labels_depth(out_label, depth, 0.8)
+        refined = None
+        if network_crop is not None:
+            rgb_c, mask_c, rois, depth_c = crop_rois(image, out_label.clone(), depth)
+            if rgb_c.shape[0] > 0:
+                f2 = network_crop(rgb_c, mask_c, depth_c)
+                n2 = f2.shape[2] * f2.shape[3]
+                labels_c = clustering_features(f2, [rng.randint(0, n2) for _ in range(f2.shape[0])])
+                refined, _ = match_label_crop(out_label, labels_c, mask_c, rois, depth_c)
+        prediction = out_label.squeeze().numpy()
+        out.append((prediction, refined.squeeze().numpy() if refined is not None else prediction.copy()))
+    return out

@@ -169,3 +169,87 @@ def munkres_cases():
     F = rng.random((4, 9)) * (rng.random((4, 9)) > 0.6)
     out["fmeasure_4x9"] = F.max() - F
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Input preparation: the reference's own read_sample (tools/test_images.py:105-135) on the
+# demo pair and on a synthetic pair that spans the uint8 / uint16 ranges at an odd size.
+# ---------------------------------------------------------------------------------------------
+PREP_SYNTH = dict(seed=5, H=37, W=53, camera=dict(fx=500.5, fy=499.25, x_offset=26.1, y_offset=18.7))
+
+
+def prep_synthetic_arrays():
+    """(BGR uint8 [H,W,3], depth uint16 [H,W] millimetres): full value ranges, a few zero-depth holes."""
+    c = PREP_SYNTH
+    rng = np.random.default_rng(c["seed"])
+    im = rng.integers(0, 256, size=(c["H"], c["W"], 3), dtype=np.uint8)
+    dep = rng.integers(0, 65536, size=(c["H"], c["W"])).astype(np.uint16)
+    dep[::7, ::5] = 0
+    dep[0, 0], dep[0, 1] = 65535, 1
+    return im, dep
+
+
+# ---------------------------------------------------------------------------------------------
+# test_segnet (SURVEY.md §8 a14): the reference's dataset loop (lib/fcn/test_dataset.py:271-381) over three samples
+# with stub networks, under an 'ocid...' and an 'osd...' dataset name (depth-coverage thresholds 0.5 / 0.8, :299-305).
+# ---------------------------------------------------------------------------------------------
+SEGNET_RUNS = {
+    "ocid": dict(name="ocid_object_test", frames=[dict(seed=61, objects=4), dict(seed=62, objects=5), dict(seed=63, objects=3)]),
+    "osd":  dict(name="osd_object_test",  frames=[dict(seed=64, objects=5), dict(seed=65, objects=3), dict(seed=66, objects=4)]),
+}
+SEGNET_H, SEGNET_W = 240, 320
+
+
+class SegnetLoader:
+    """What test_segnet needs from a DataLoader: len(), iteration over sample dicts, `.dataset.name`."""
+
+    def __init__(self, name, samples):
+        self.samples = samples
+        self.dataset = type("Dataset", (), {"name": name})()
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __iter__(self):
+        return iter(self.samples)
+
+
+def segnet_samples(run):
+    """Sample dicts like the reference's dataset classes yield them (batch 1): image_color, depth, label (the
+    generating scene as ground truth, [1,H,W] float like ocid_object.py), filename.  Frame f's depth has a block of the
+    object with the largest id knocked out (z = 0 on ~45 % of it), so the two coverage thresholds act differently."""
+    out = []
+    for k, f in enumerate(run["frames"]):
+        fr = synth.rgbd_frame(f["seed"], SEGNET_H, SEGNET_W, f["objects"])
+        depth = fr["depth"].copy()
+        lab = fr["label"]
+        ys, xs = np.nonzero(lab == lab.max())
+        cut = ys < np.quantile(ys, 0.45)
+        depth[0, :, ys[cut], xs[cut]] = 0.0
+        out.append(dict(image_color=torch.from_numpy(fr["image_color"]), depth=torch.from_numpy(depth),
+                        label=torch.from_numpy(lab.astype(np.float32))[None], filename="scene_%02d/%06d" % (k, f["seed"])))
+    return out
+
+
+def segnet_stub_networks(run):
+    """(network, network_crop) callables returning fixed embedding fields: stage 1 by frame (looked up by the image's
+    checksum-free order of calls), stage 2 by crop index — like the e2e fixtures."""
+    frames = run["frames"]
+    state = {"i": 0}
+
+    def net(img, label, depth):
+        f = frames[state["i"] % len(frames)]
+        state["i"] += 1
+        return e2e_stub_features(f["seed"], SEGNET_H, SEGNET_W, f["objects"] + 2)
+
+    def net_crop(rgb, label, depth):
+        i = (state["i"] - 1) % len(frames)
+        return torch.cat([e2e_stub_features(2000 + 10 * frames[i]["seed"] + k, 224, 224, 2 + k % 3) for k in range(rgb.shape[0])])
+
+    for fn in (net, net_crop):
+        fn.eval = lambda: None
+    return net, net_crop
+
+
+SEGNET_METRIC_KEYS = ["Objects F-measure", "Objects Precision", "Objects Recall", "obj_detected", "obj_detected_075",
+                      "obj_gt", "obj_detected_075_percentage"]

@@ -4,7 +4,7 @@ Imports the reference's own Python (through tests/golden/ref_harness.py) and rec
 outputs on repo-owned synthetic inputs.  The .npz files written next to this script are the
 fixtures tests/ compares the oracle (CPU) and the HIP path (GPU) against.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [meanshift|glue|backbone|e2e|demo|modes|evaluation|all]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [meanshift|glue|backbone|e2e|demo|modes|evaluation|prep|segnet|all]
 """
 from __future__ import annotations
 
@@ -22,7 +22,8 @@ sys.path.insert(0, HERE)
 import ref_harness  # noqa: E402
 from cases import (MEANSHIFT_CASES, KAPPA, EPSILON, RNG_SEED, BACKBONE_CASES, GLUE_CASES, E2E_CASES,  # noqa: E402
                    MODES, MODE_BACKBONE_CASES, MODE_GLUE_CASES, MODE_E2E_CASES, WIDE_MEANSHIFT_CASES,
-                   EVAL_CASES, eval_pair, munkres_cases,
+                   EVAL_CASES, eval_pair, munkres_cases, PREP_SYNTH, prep_synthetic_arrays, SEGNET_RUNS, SegnetLoader,
+                   segnet_samples, segnet_stub_networks, SEGNET_METRIC_KEYS,
                    sample_positions, glue_inputs, crop_cluster_labels, e2e_stub_features)
 from unseenobjectclustering_amd import synth  # noqa: E402
 
@@ -273,6 +274,120 @@ def make_evaluation(ref):
     np.savez_compressed(os.path.join(HERE, "evaluation.npz"), **out)
 
 
+def _install_cv2_reader():
+    """cv2 is not installed here; the reference's read_sample only needs cv2.imread (tools/test_images.py:108,112).
+    The stand-in decodes with PIL and returns what cv2 would: BGR uint8 [H,W,3] for a colour read, the raw uint16
+    array for IMREAD_ANYDEPTH."""
+    from PIL import Image
+    cv2 = sys.modules["cv2"]
+    cv2.IMREAD_ANYDEPTH = 2
+
+    def imread(path, flags=1):
+        im = Image.open(path)
+        if flags == cv2.IMREAD_ANYDEPTH:
+            return np.asarray(im).copy()
+        return np.asarray(im.convert("RGB"))[:, :, ::-1].copy()
+    cv2.imread = imread
+    cv2.imwrite = lambda *a, **k: True
+
+
+def make_prep(ref):
+    """a15 / f-2: the reference's OWN read_sample + compute_xyz (tools/test_images.py:96-135), imported from
+    /root/reference/tools with cv2.imread served by PIL, on (1) the demo pair and (2) a synthetic pair written to a
+    temporary directory as 8-bit / 16-bit PNGs.  Recorded: SHA-256 of the raw float32 bytes of both tensors, sums and
+    4096 sampled values for the demo pair; the complete tensors for the small synthetic pair."""
+    import hashlib
+    import importlib
+    import json
+    import tempfile
+    from PIL import Image
+    _install_cv2_reader()
+    tools = os.path.join(ref_harness.REFERENCE_ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    ti = importlib.import_module("test_images")           # module level only defines functions; main() is guarded
+    out = {}
+    demo = os.path.join(HERE, "demo")
+    cam = json.load(open(os.path.join(demo, "camera_params.json")))
+    s = ti.read_sample(os.path.join(demo, "000002-color.png"), os.path.join(demo, "000002-depth.png"), cam)
+    pos = sample_positions(11, 3 * 480 * 640, 4096)
+    for key in ("image_color", "depth"):
+        a = np.ascontiguousarray(s[key].numpy())
+        assert a.dtype == np.float32 and a.shape == (1, 3, 480, 640), (a.dtype, a.shape)
+        out[f"demo/{key}/sha256"] = np.frombuffer(hashlib.sha256(a.tobytes()).digest(), dtype=np.uint8)
+        out[f"demo/{key}/sum"] = np.array(a.astype(np.float64).sum())
+        out[f"demo/{key}/samples"] = a.reshape(-1)[pos]
+    out["demo/pos"] = pos
+    im, dep = prep_synthetic_arrays()
+    with tempfile.TemporaryDirectory() as td:
+        fc, fd = os.path.join(td, "c.png"), os.path.join(td, "d.png")
+        Image.fromarray(im[:, :, ::-1].copy()).save(fc)           # file is RGB; cv2.imread hands back BGR = `im`
+        Image.fromarray(dep).save(fd)                               # 16-bit greyscale PNG
+        assert np.array_equal(sys.modules["cv2"].imread(fc), im)
+        assert np.array_equal(sys.modules["cv2"].imread(fd, 2), dep)
+        s2 = ti.read_sample(fc, fd, PREP_SYNTH["camera"])
+    out["synth/image_color"] = s2["image_color"].numpy()
+    out["synth/depth"] = s2["depth"].numpy()
+    print("prep: demo image sum %.6f depth sum %.6f; synth shapes %s %s" % (
+        float(out["demo/image_color/sum"]), float(out["demo/depth/sum"]), out["synth/image_color"].shape, out["synth/depth"].shape), flush=True)
+    np.savez_compressed(os.path.join(HERE, "prep.npz"), **out)
+
+
+def make_segnet(ref):
+    """a14: the reference's OWN test_segnet (lib/fcn/test_dataset.py:271-381) on three samples per dataset name, stub
+    networks, cfg.TEST.VISUALIZE False (so it writes the .mat files), boundary_overlap stubbed to (0, 0) like
+    make_evaluation (cv2.dilate / skimage are absent).  Recorded per run: the labels / labels_refined / filename of
+    every .mat, the per-frame metrics before and after refinement, and the printed report."""
+    import contextlib
+    import importlib
+    import io
+    import tempfile
+    import scipy.io
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    ev = importlib.import_module("utils.evaluation")
+    td = ref.test_dataset
+    real = ev.boundary_overlap
+    ev.boundary_overlap = lambda p, g, bound_th=0.003: (0, 0)
+    out = {}
+    try:
+        for tag, run in SEGNET_RUNS.items():
+            samples = segnet_samples(run)
+            net, net_crop = segnet_stub_networks(run)
+            metrics_log = []
+            real_mm = td.multilabel_metrics
+
+            def spy(prediction, gt, _real=real_mm, _log=metrics_log):
+                m = _real(prediction, gt)
+                _log.append(dict(m))
+                return m
+            td.multilabel_metrics = spy
+            buf = io.StringIO()
+            with tempfile.TemporaryDirectory() as tmp:
+                np.random.seed(RNG_SEED)
+                try:
+                    with contextlib.redirect_stdout(buf):
+                        td.test_segnet(SegnetLoader(run["name"], samples), net, tmp, net_crop)
+                finally:
+                    td.multilabel_metrics = real_mm
+                for i in range(len(samples)):
+                    mat = scipy.io.loadmat(os.path.join(tmp, "%06d.mat" % i))
+                    out[f"{tag}/{i}/labels"] = mat["labels"].astype(np.uint8)
+                    out[f"{tag}/{i}/labels_refined"] = mat["labels_refined"].astype(np.uint8)
+                    out[f"{tag}/{i}/filename"] = np.array(str(np.asarray(mat["filename"]).reshape(-1)[0]))
+            assert len(metrics_log) == 2 * len(samples)
+            for i in range(len(samples)):
+                out[f"{tag}/{i}/metrics"] = np.array([float(metrics_log[2 * i][k]) for k in SEGNET_METRIC_KEYS])
+                out[f"{tag}/{i}/metrics_refined"] = np.array([float(metrics_log[2 * i + 1][k]) for k in SEGNET_METRIC_KEYS])
+            report = [ln for ln in buf.getvalue().splitlines() if "batch time" not in ln and not ln.endswith(".mat")]
+            out[f"{tag}/report"] = np.array("\n".join(report))
+            print(tag, "frames", len(samples), "segments", [int(out[f"{tag}/{i}/labels"].max()) for i in range(len(samples))],
+                  "refined", [int(out[f"{tag}/{i}/labels_refined"].max()) for i in range(len(samples))], flush=True)
+    finally:
+        ev.boundary_overlap = real
+    np.savez_compressed(os.path.join(HERE, "segnet.npz"), **out)
+
+
 def main():
     assert ref_harness.available(), "reference tree not present: golden vectors can only be made in the build container"
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
@@ -292,6 +407,10 @@ def main():
         make_modes(ref)
     if what in ("evaluation", "all"):
         make_evaluation(ref)
+    if what in ("prep", "all"):
+        make_prep(ref)
+    if what in ("segnet", "all"):
+        make_segnet(ref)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,82 @@
+"""GPU, against fixtures captured from the REFERENCE's own code:
+  * uoc_prep_rgbd (device-side input preparation) vs the reference's read_sample / compute_xyz
+    (tools/test_images.py:96-135) — tests/golden/prep.npz, bit-exact;
+  * test_segnet (dataset loop, §8 a14) vs the reference's test_segnet (lib/fcn/test_dataset.py:271-381) —
+    tests/golden/segnet.npz: the label maps of every .mat bit-exact, the overlap metrics / detection counts before and
+    after refinement to 1e-12, and the averaged report lines of those keys."""
+import contextlib
+import hashlib
+import io
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.io
+import torch
+
+from tests.golden.cases import (PREP_SYNTH, RNG_SEED, SEGNET_METRIC_KEYS, SEGNET_RUNS, SegnetLoader, prep_synthetic_arrays,
+                                segnet_samples, segnet_stub_networks)
+from unseenobjectclustering_amd import io as uio
+from unseenobjectclustering_amd.fcn import test_dataset as TD
+from unseenobjectclustering_amd.fcn.config import cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_input_prep_matches_the_reference_read_sample(golden_dir, device):
+    g = np.load(os.path.join(golden_dir, "prep.npz"))
+    d = os.path.join(golden_dir, "demo")
+    cam = json.load(open(os.path.join(d, "camera_params.json")))
+    raw = uio.read_sample_raw(os.path.join(d, "000002-color.png"), os.path.join(d, "000002-depth.png"), cam)
+    got = uio.prepare_on_device(raw, device)
+    for key in ("image_color", "depth"):
+        a = np.ascontiguousarray(got[key].cpu().numpy())
+        assert a.shape == (1, 3, 480, 640) and a.dtype == np.float32
+        assert hashlib.sha256(a.tobytes()).digest() == g[f"demo/{key}/sha256"].tobytes(), key
+    im, dep = prep_synthetic_arrays()
+    got = uio.prepare_on_device(uio.make_sample_raw(im, dep, PREP_SYNTH["camera"]), device)
+    assert np.array_equal(got["image_color"].cpu().numpy(), g["synth/image_color"])
+    assert np.array_equal(got["depth"].cpu().numpy(), g["synth/depth"])
+
+
+def _report_values(text):
+    """{key: value} of the `key: value` lines of the first (unrefined) averaged report."""
+    out = {}
+    for ln in text.splitlines():
+        if ln.startswith("====================Refined"):
+            break
+        m = re.match(r"^([A-Za-z_0-9 \-]+): (-?[0-9.]+(?:e-?[0-9]+)?)$", ln)
+        if m:
+            out[m.group(1)] = float(m.group(2))
+    return out
+
+
+@pytest.mark.parametrize("tag", list(SEGNET_RUNS))
+def test_test_segnet_matches_reference_golden(golden_dir, device, tmp_path, tag):
+    cfg.device = device
+    g = np.load(os.path.join(golden_dir, "segnet.npz"))
+    run = SEGNET_RUNS[tag]
+    samples = segnet_samples(run)
+    cpu_net, cpu_crop = segnet_stub_networks(run)
+    net = lambda img, label, depth: cpu_net(img, label, depth).to(device)
+    net_crop = lambda rgb, label, depth: cpu_crop(rgb, label, depth).to(device)
+    net.eval = net_crop.eval = lambda: None
+    np.random.seed(RNG_SEED)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        results = TD.test_segnet(SegnetLoader(run["name"], samples), net, str(tmp_path), net_crop)
+    assert len(results) == len(samples)
+    for i, r in enumerate(results):
+        mat = scipy.io.loadmat(os.path.join(str(tmp_path), "%06d.mat" % i))
+        assert np.array_equal(mat["labels"].astype(np.uint8), g[f"{tag}/{i}/labels"])
+        assert np.array_equal(mat["labels_refined"].astype(np.uint8), g[f"{tag}/{i}/labels_refined"])
+        assert str(np.asarray(mat["filename"]).reshape(-1)[0]) == str(g[f"{tag}/{i}/filename"])
+        for j, k in enumerate(SEGNET_METRIC_KEYS):
+            assert abs(float(r["metrics"][k]) - g[f"{tag}/{i}/metrics"][j]) < 1e-12, (i, k)
+            assert abs(float(r["metrics_refined"][k]) - g[f"{tag}/{i}/metrics_refined"][j]) < 1e-12, (i, k)
+    want, got = _report_values(str(g[f"{tag}/report"])), _report_values(buf.getvalue())
+    for k in SEGNET_METRIC_KEYS:
+        assert k in want and k in got and abs(want[k] - got[k]) < 1e-6, (k, want.get(k), got.get(k))
+    assert "%d images" % len(samples) in buf.getvalue()
