@@ -204,6 +204,13 @@ int uoc_eval_pair_stats(const int32_t *d_pred, const int32_t *d_gt, int H, int W
 
 
 /* ------------------------------------------------------------------------------------------
+ * Host-side data formats (no device work) — what the dataset loaders need in place of python-pcl
+ * (lib/datasets/ocid_object.py:105, osd_object.py:92): LZF decoder for `DATA binary_compressed` PCD files.
+ * `in`/`out` are HOST pointers.  Returns the number of bytes written or a negative code.
+ * ---------------------------------------------------------------------------------------- */
+long uoc_lzf_decompress(const uint8_t *in, size_t in_len, uint8_t *out, size_t out_cap);
+
+/* ------------------------------------------------------------------------------------------
  * Opt-in per-kernel timing (HIP events on the launch stream).  Single-threaded use.
  * uoc_prof_report writes a JSON array [{kernel, launches, total_ms, flops, bytes}, ...] where
  * flops/bytes are the ALGORITHMIC totals of the recorded launches.

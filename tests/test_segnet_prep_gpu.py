@@ -80,3 +80,49 @@ def test_test_segnet_matches_reference_golden(golden_dir, device, tmp_path, tag)
     for k in SEGNET_METRIC_KEYS:
         assert k in want and k in got and abs(want[k] - got[k]) < 1e-6, (k, want.get(k), got.get(k))
     assert "%d images" % len(samples) in buf.getvalue()
+
+
+def test_tools_test_net_on_a_synthetic_osd_tree(device, tmp_path):
+    """tools/test_net.py (counterpart of the reference's tools/test_net.py:60-131) end to end: dataset by name from a
+    synthetic OSD tree (binary_compressed clouds -> native LZF decoder), DataLoader batches of one, the two networks
+    from `{'model': state_dict}` checkpoints, test_segnet's .mat files + report.  The frames are palette frames the
+    calibrated weights segment, so the metrics are meaningful (objects found, F-measure well above zero)."""
+    import importlib.util
+    from tests import dataset_tree as DT
+    from unseenobjectclustering_amd import synth
+    root = str(tmp_path)
+    for sub in ("image_color", "annotation", "pcd"):
+        os.makedirs(os.path.join(root, "OSD", sub))
+    from PIL import Image
+    for j, seed in enumerate([10_000, 10_001]):
+        fr = synth.palette_frame(seed, 480, 640, 5 + seed % 3)
+        img = fr["image_color"][0].transpose(1, 2, 0) + (synth.PIXEL_MEANS / 255.0).astype(np.float32)
+        bgr = np.clip(np.rint(img * 255.0), 0, 255).astype(np.uint8)
+        xyz = fr["depth"][0].transpose(1, 2, 0).reshape(-1, 3).copy()
+        xyz[xyz[:, 2] == 0] = np.nan
+        lab = fr["label"].astype(np.uint8)
+        lab[lab == 1] = 0                                               # OSD annotations: 0 = everything that is no object
+        Image.fromarray(bgr[:, :, ::-1].copy()).save(os.path.join(root, "OSD", "image_color", "f%d.png" % j))
+        DT._save_indexed(os.path.join(root, "OSD", "annotation", "f%d.png" % j), lab)
+        DT.write_pcd(os.path.join(root, "OSD", "pcd", "f%d.pcd" % j), xyz, "binary_compressed", with_rgb=False)
+    ckpt = os.path.join(root, "ckpt.pth")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    torch.save({"model": {"module." + k: v for k, v in sd.items()}}, ckpt)      # DataParallel-style keys, wrapped dict
+    spec = importlib.util.spec_from_file_location("uoc_tools_test_net", os.path.join(
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "test_net.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out_dir = os.path.join(root, "out")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        results = mod.main(["--dataset", "osd_object_test", "--network", "seg_resnet34_8s_embedding", "--pretrained", ckpt,
+                            "--pretrained_crop", ckpt, "--data-root", root, "--output-dir", out_dir])
+    assert len(results) == 2
+    text = buf.getvalue()
+    assert "2 images for dataset osd_object_test" in text and "2 images" in text and "Objects F-measure" in text
+    for i, r in enumerate(results):
+        mat = scipy.io.loadmat(os.path.join(out_dir, "%06d.mat" % i))
+        assert mat["labels"].shape == (480, 640) and mat["labels_refined"].shape == (480, 640)
+        assert "image_color/f%d.png" % i in str(mat["filename"])
+        assert int(mat["labels_refined"].max()) >= 5
+        assert r["metrics_refined"]["Objects F-measure"] > 0.8 and r["metrics_refined"]["obj_detected_075_percentage"] >= 0.6, r["metrics_refined"]

@@ -65,6 +65,8 @@ def _declare(lib):
     lib.uoc_roi_paste.argtypes = [P, P, P, P, c_int, c_int, c_int, c_int, P, P]
     for name in ("uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats", "uoc_roi_paste"):
         getattr(lib, name).restype = c_int
+    lib.uoc_lzf_decompress.argtypes = [P, c_size_t, P, c_size_t]
+    lib.uoc_lzf_decompress.restype = ctypes.c_long
     lib.uoc_prof_enable.argtypes = [c_int]
     lib.uoc_prof_reset.argtypes = []
     lib.uoc_prof_report.argtypes = [ctypes.c_char_p, c_size_t]
@@ -83,7 +85,7 @@ EXPORTED_SYMBOLS = (
     "uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",
     "uoc_net_forward", "uoc_conv2d_nhwc",
     "uoc_roi_workspace_bytes", "uoc_prep_rgbd", "uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats",
-    "uoc_roi_paste", "uoc_eval_workspace_bytes", "uoc_eval_pair_stats", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
+    "uoc_roi_paste", "uoc_eval_workspace_bytes", "uoc_eval_pair_stats", "uoc_lzf_decompress", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
 )
 
 

@@ -32,7 +32,14 @@ cfg.PIXEL_MEANS = np.array([[[102.9801, 115.9465, 122.7717]]])   # config.py:376
 cfg.gpu_id = 0
 cfg.device = None                      # set by the driver (tools/test_images.py:157-158)
 
+cfg.EXP_DIR = "default"                # config.py:388
+cfg.ROOT_DIR = __import__("os").path.abspath(__import__("os").path.join(__import__("os").path.dirname(__file__), "..", ".."))   # config.py:385
+cfg.INTRINSICS = ()                    # config.py:38 (tools/test_net.py:98-101 overwrites the dataset's K with it)
+
 cfg.TRAIN = AttrDict()
+cfg.TRAIN.CLASSES = (0, 1, 2, 3)       # config.py:66
+cfg.TRAIN.CHROMATIC = True             # config.py:159 (training-time augmentation flags the loaders read; TEST mode ignores them)
+cfg.TRAIN.ADD_NOISE = False            # config.py:160
 cfg.TRAIN.NUM_UNITS = 64               # config.py:165
 cfg.TRAIN.FUSION_TYPE = "add"          # config.py:92
 cfg.TRAIN.SYN_CROP_SIZE = 224          # config.py:129
@@ -43,6 +50,15 @@ cfg.TRAIN.EMBEDDING_ALPHA = 0.02       # config.py:254 ; epsilon = 2*alpha (mean
 
 cfg.TEST = AttrDict()
 cfg.TEST.VISUALIZE = False             # config.py:319
+cfg.TEST.IMS_PER_BATCH = 1             # config.py:330
+cfg.TEST.CLASSES = (0, 1, 2, 3)        # config.py:346 (if emptied, tools/test_net.py:68-69 copies TRAIN.CLASSES)
+
+
+def get_output_dir(imdb, net):
+    """config.py:395-405: <ROOT_DIR>/output/<EXP_DIR>/<dataset name>[/<net>]."""
+    import os.path as osp
+    path = osp.abspath(osp.join(cfg.ROOT_DIR, "output", cfg.EXP_DIR, imdb.name))
+    return path if net is None else osp.join(path, net)
 
 
 def network_mode() -> str:
