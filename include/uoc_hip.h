@@ -35,6 +35,9 @@ extern "C" {
 #define UOC_MAX_SEEDS 128  /* num_seeds upper bound (reference default 100)   */
 
 int uoc_version(void);
+/* Releases process-wide helper objects (the per-device events that order the persistent sampling kernels of
+ * different streams).  Optional; call it before process exit while the HIP runtime is still up.  Idempotent. */
+int uoc_shutdown(void);
 const char *uoc_last_error(void);
 
 /* ------------------------------------------------------------------------------------------
@@ -44,6 +47,11 @@ const char *uoc_last_error(void);
 /* Seed selection runs as ONE persistent cooperative launch with X resident on chip when the batch
  * fits the device (default); 0 forces the streaming one-launch-per-step kernel.  Same results. */
 int uoc_ms_set_persistent_fps(int on);
+/* A caller that launches clustering from SEVERAL streams of one device (frames in flight) must switch this on: the
+ * persistent sampling grids of different streams are then ordered through a per-device event, because two of them
+ * partially resident at the same time would each wait for blocks the other keeps off the chip.  Off by default
+ * (single-stream callers pay nothing). */
+int uoc_ms_set_stream_ordering(int on);
 /* Number of seed-selection calls since process start in which fields that the on-chip kernel should have handled
  * went to the streaming kernel instead (does not fit on chip / cooperative launch refused).  The two kernels sum the
  * dot product in different orders; a caller that needs placement-independent results checks that this stays 0. */

@@ -21,16 +21,20 @@ def test_block_is_independent_of_frames_in_flight(device):
         fr = synth.palette_frame(s, 480, 640, 5 + s % 3)
         samples.append(dict(image_color=torch.from_numpy(fr["image_color"]).to(device),
                             depth=torch.from_numpy(fr["depth"]).to(device)))
-    fn = runner.two_stage_frame_fn(samples, net, net_crop)
     before = _native.lib().uoc_ms_fps_fallbacks()
-    blocks = {}
-    for depth in (1, 2, 3):
-        blocks[depth] = runner.run_sharded(5, fn, 480, 640, device, 0, 1, False, inflight=depth).cpu()
+    blocks, counts = {}, {}
+    # (streams, frames per launch): sequential / two streams / three streams, one or two frames per launch set
+    for depth, group in ((1, 1), (2, 1), (3, 1), (2, 2), (2, 3), (1, 2)):
+        fn = runner.two_stage_frame_fn(samples, net, net_crop, frames_per_launch=group)
+        blocks[depth, group] = runner.run_sharded(5, fn, 480, 640, device, 0, 1, False, inflight=depth).cpu()
         torch.cuda.synchronize()
-    assert blocks[1].shape == (5, 480, 640) and int(blocks[1].max()) >= 5
-    assert torch.equal(blocks[1], blocks[2]), "two frames in flight changed a label map"
-    assert torch.equal(blocks[1], blocks[3]), "three frames in flight changed a label map"
+        counts[depth, group] = list(fn.roi_counts)
+    ref = blocks[1, 1]
+    assert ref.shape == (5, 480, 640) and int(ref.max()) >= 5
+    for key, b in blocks.items():
+        assert torch.equal(ref, b), f"streams={key[0]} frames_per_launch={key[1]} changed a label map"
+        assert counts[key] == counts[1, 1]
     # the on-chip sampling kernel served every field (no silent fallback to the streaming kernel's other summation order)
     assert _native.lib().uoc_ms_fps_fallbacks() == before
-    # stage-2 really ran: ROI counts recorded per frame, same sequence in every mode
-    assert fn.roi_counts[:5] == fn.roi_counts[5:10] == fn.roi_counts[10:15] and min(fn.roi_counts) >= 5
+    # stage 2 really ran: ROI counts recorded per frame
+    assert len(counts[1, 1]) == 5 and min(counts[1, 1]) >= 5

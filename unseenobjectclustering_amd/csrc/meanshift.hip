@@ -1155,6 +1155,7 @@ static int fps_blocks(int n) {
 
 static int g_fps_persistent = -1;  // -1: read UOC_FPS_PERSISTENT on first use
 static std::atomic<int> g_fps_fallbacks{0};
+static std::atomic<int> g_fps_stream_ordering{0};  // uoc_ms_set_stream_ordering: callers that launch from several streams
 static int fps_persistent_plan(int batch, int n, int *bpi, int *nslots) {
   const int g_num_cu = device_num_cu();  // of the CURRENT device
   if (g_num_cu <= 0) return 0;
@@ -1190,8 +1191,8 @@ struct FpsChain {
   }
 };
 static FpsChain &fps_chain() {
-  static FpsChain c;
-  return c;
+  static FpsChain *c = new FpsChain();  // never destructed: static destruction order vs. the HIP runtime is undefined
+  return *c;
 }
 // UOC_FPS_COOP=0: plain launch of the persistent grid (co-residency then rests on the plan + the event chain alone)
 static bool fps_cooperative() {
@@ -1220,7 +1221,8 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
     UOC_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int), st));
     // the LDS pixel slot is only touched when a lane owns more than FPP_RS pixels; without it the kernel needs no
     // dynamic LDS at all and can share a CU with another stream's convolution blocks (two frames in flight)
-    const size_t lds = nslots > FPP_RS ? (size_t)FPP_LS * (C / 4) * FPP_THREADS * sizeof(float4) : 0;
+    static const bool lds_always = getenv("UOC_FPS_LDS_ALWAYS") != nullptr;  // dev: the round-1 launch shape
+    const size_t lds = (nslots > FPP_RS || lds_always) ? (size_t)FPP_LS * (C / 4) * FPP_THREADS * sizeof(float4) : 0;
     static DeviceOnce attr_set;
     if (!attr_set.done()) {
       UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_persistent_kernel),
@@ -1241,7 +1243,7 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
       // after the other; everything else on the two streams still overlaps.
       FpsChain &chain = fps_chain();
       std::lock_guard<std::mutex> lock(chain.mu);
-      hipEvent_t ev = chain.event();
+      hipEvent_t ev = g_fps_stream_ordering.load() ? chain.event() : nullptr;
       if (ev) UOC_HIP_CHECK(hipStreamWaitEvent(st, ev, 0));
       {
         ProfScope prof(KC_FPS_STEP, st, 2.0 * sub * (double)n * C * (m - 1), 4.0 * sub * (double)n * C);
@@ -1450,6 +1452,24 @@ int uoc_ms_set_persistent_fps(int on) {
 }
 
 int uoc_ms_fps_fallbacks(void) { return g_fps_fallbacks.load(); }
+
+int uoc_ms_set_stream_ordering(int on) {
+  g_fps_stream_ordering.store(on ? 1 : 0);
+  return UOC_OK;
+}
+
+int uoc_shutdown(void) {
+  // releases the per-device ordering events while the HIP runtime is still alive (a live event at process exit
+  // crashes the rocprofv3 tool's finaliser); the host mirrors call it from a Python atexit hook
+  FpsChain &chain = fps_chain();
+  std::lock_guard<std::mutex> lock(chain.mu);
+  for (int d = 0; d < kMaxDevices; ++d)
+    if (chain.ev[d]) {
+      (void)hipEventDestroy(chain.ev[d]);
+      chain.ev[d] = nullptr;
+    }
+  return UOC_OK;
+}
 
 int uoc_ms_check(void *stream) {
   hipStream_t st = (hipStream_t)stream;

@@ -193,11 +193,13 @@ class _HostMirror:
     depths) and the host->device paint plan go through them as asynchronous copies guarded by an event, so the host
     can queue another frame's work on another stream while a read is in flight."""
 
-    def __init__(self):
+    def __init__(self, frames=1):
         n = MAX_LABELS * MAX_LABELS + MAX_LABELS
-        self.table = torch.empty(_native.ROI_TABLE_BYTES, dtype=torch.uint8).pin_memory()
-        self.stats = torch.empty(n, dtype=torch.int32).pin_memory()
-        self.plan = torch.empty(n, dtype=torch.int32).pin_memory()
+        self.frames = frames
+        self.tables = torch.empty((frames, _native.ROI_TABLE_BYTES), dtype=torch.uint8).pin_memory()
+        self.stats_all = torch.empty((frames, n), dtype=torch.int32).pin_memory()
+        self.plans = torch.empty((frames, n), dtype=torch.int32).pin_memory()
+        self.table, self.stats, self.plan = self.tables[0], self.stats_all[0], self.plans[0]
         self.table_ready = torch.cuda.Event()
         self.stats_ready = torch.cuda.Event()
 
@@ -205,10 +207,10 @@ class _HostMirror:
 _mirrors = {}
 
 
-def _mirror(dev) -> _HostMirror:
+def _mirror(dev, frames=1) -> _HostMirror:
     key = _native.stream_key(dev)
-    if key not in _mirrors:
-        _mirrors[key] = _HostMirror()
+    if key not in _mirrors or _mirrors[key].frames < frames:
+        _mirrors[key] = _HostMirror(frames)
     return _mirrors[key]
 
 
@@ -387,6 +389,123 @@ class FrameJob:
     def result_device(self):
         """(labels [B,H,W] int32, refined [B,H,W] int32 or None), on the device."""
         return self.labels.view(self.B, self.H, self.W), self.refined
+
+
+class FrameGroupJob:
+    """N independent single-image frames through the two-stage path as ONE set of launches per stage (the frame-parallel
+    runner's unit of work): both stage-1 embeddings in one network forward (batch N), both clusterings in one launch
+    set, and the crops of all N frames in one stage-2 forward (batch K_1 + ... + K_N).  Twice the pixels / Winograd
+    tiles per launch is what the convolution kernels need to fill 256 CUs with full-height tiles.  Every
+    frame keeps its own ROI table, RNG and output; label maps are bit-identical to one-frame-at-a-time processing (the
+    kernels' per-output summation order does not depend on the batch).  Same three stages as FrameJob."""
+
+    def __init__(self, samples, network, network_crop, depth_threshold, rngs):
+        self.samples, self.network, self.network_crop = list(samples), network, network_crop
+        self.depth_threshold, self.rngs = depth_threshold, list(rngs)
+        self.N = len(self.samples)
+        self.K = [0] * self.N
+        self.refined = [None] * self.N
+
+    def stage1(self):
+        require_supported()
+        dev = self.dev = _device()
+        N = self.N
+        pin = lambda t: t.to(dev, non_blocking=True) if (not t.is_cuda and t.is_pinned()) else t.to(dev)
+        images, depths = [], []
+        for sm in self.samples:
+            if "image_u8" in sm:
+                from ..io import prepare_on_device
+                sm = dict(sm, **prepare_on_device(sm, dev))
+            images.append(pin(sm["image_color"]).float())
+            if uses_depth():
+                depths.append(pin(sm["depth"]).float())
+        self.image = image = (torch.cat(images) if N > 1 else images[0]).contiguous()
+        self.depth = depth = ((torch.cat(depths) if N > 1 else depths[0]).contiguous()) if depths else None
+        thr = self.depth_threshold if depth is not None else None
+        assert image.shape[0] == N, "FrameGroupJob takes single-image samples"
+        _, _, H, W = image.shape
+        self.H, self.W = H, W
+        features = _detach_keep_planes(self.network(image, None, depth))
+        firsts = [self.rngs[f].randint(0, H * W) for f in range(N)]          # mean_shift.py:155, one draw per frame
+        self.labels = labels = _cluster_fields(features, firsts)             # [N, H*W] int32
+        self.tables = []
+        for f in range(N):
+            zptr = ctypes.c_void_p(depth.data_ptr() + ((3 * f + 2) * H * W) * 4) if thr is not None else ctypes.c_void_p(0)
+            self.tables.append(_build_rois(labels[f], zptr, H, W, dev, thr if thr is not None else 0.0))
+        if self.network_crop is not None:
+            self.host = _mirror(dev, N)
+            for f in range(N):
+                self.host.tables[f].copy_(self.tables[f], non_blocking=True)
+            self.host.table_ready.record(torch.cuda.current_stream(dev))
+
+    def stage2(self):
+        if self.network_crop is None:
+            return
+        dev, H, W, N = self.dev, self.H, self.W, self.N
+        S = cfg.TRAIN.SYN_CROP_SIZE
+        self.host.table_ready.synchronize()
+        self.table_host = [_native.RoiTable.from_buffer_copy(self.host.tables[f].numpy().tobytes()) for f in range(N)]
+        self.K = [int(t.K) for t in self.table_host]
+        Kt = sum(self.K)
+        if Kt == 0:
+            return
+        self.off = np.concatenate([[0], np.cumsum(self.K)]).astype(int)
+        rgb = torch.empty((Kt, 3, S, S), dtype=torch.float32, device=dev)
+        dep = torch.empty((Kt, 3, S, S), dtype=torch.float32, device=dev) if self.depth is not None else None
+        mask = torch.empty((Kt, S, S), dtype=torch.float32, device=dev)
+        L = _native.lib()
+        for f in range(N):
+            if self.K[f] == 0:
+                continue
+            a, b = self.off[f], self.off[f + 1]
+            with torch.cuda.device(dev):
+                rc = L.uoc_roi_crop(_native.ptr(self.image[f]), _native.ptr(self.depth[f]) if dep is not None else None,
+                                    _native.ptr(self.labels[f]), H, W, _native.ptr(self.tables[f]), self.K[f], S,
+                                    _native.ptr(rgb[a:b]), _native.ptr(dep[a:b]) if dep is not None else None,
+                                    _native.ptr(mask[a:b]), _native.stream_ptr(dev))
+            _native.check(rc, "uoc_roi_crop")
+        features_crop = _detach_keep_planes(self.network_crop(rgb, mask, dep))
+        firsts = [self.rngs[f].randint(0, S * S) for f in range(N) for _ in range(self.K[f])]   # K_f draws per frame, in order
+        self.labels_crop = _cluster_fields(features_crop, firsts)              # [Kt, S*S]
+        self.has_depth = dep is not None
+        for f in range(N):
+            if self.K[f] == 0:
+                continue
+            a, b = self.off[f], self.off[f + 1]
+            stats = _match_stats(self.labels_crop[a:b], mask[a:b], dep[a:b] if dep is not None else None, self.K[f], dev)
+            self.host.stats_all[f, :stats.numel()].copy_(stats, non_blocking=True)
+        self.host.stats_ready.record(torch.cuda.current_stream(dev))
+
+    def stage3(self):
+        if self.network_crop is None or sum(self.K) == 0:
+            return
+        dev, H, W = self.dev, self.H, self.W
+        self.host.stats_ready.synchronize()
+        for f in range(self.N):
+            if self.K[f] == 0:
+                continue
+            a, b = self.off[f], self.off[f + 1]
+            refined = _paste(self.labels_crop[a:b], self.tables[f], self.table_host[f], self.host.stats_all[f], self.has_depth,
+                             self.K[f], H, W, dev, plan_host=self.host.plans[f])
+            self.refined[f] = refined.view(H, W)
+        self.labels_crop = self.image = self.depth = None
+
+    def final_maps(self):
+        """Per frame: the refined map if stage 2 produced one, else the stage-1 map ([H,W] int32, device)."""
+        return [self.refined[f] if self.refined[f] is not None else self.labels[f].view(self.H, self.W) for f in range(self.N)]
+
+
+def _cluster_fields(features, firsts):
+    """Clusters the B fields of `features` [B,C,h,w] with the given first-seed indices -> int32 labels [B, h*w]."""
+    planes = getattr(features, "_uoc_planes", None)
+    if planes is not None and planes.shape[0] == features.shape[0]:
+        X = planes
+    else:
+        X = _pixel_major(features.float())
+        if X.shape[-1] == 128:
+            X = to_planes(X)
+    labels, _ = cluster_batch(X, firsts, KAPPA, 100, MAX_ITERS, 2 * cfg.TRAIN.EMBEDDING_ALPHA)
+    return labels
 
 
 def _run_frame(sample, network, network_crop, depth_threshold, return_device=False):

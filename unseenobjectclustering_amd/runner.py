@@ -53,7 +53,7 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     if inflight is None:
         inflight = int(os.environ.get("UOC_FRAMES_IN_FLIGHT", "2"))
     try:
-        if inflight > 1 and device.type == "cuda" and hasattr(frame_fn, "make_job"):
+        if (inflight > 1 or getattr(frame_fn, "frames_per_launch", 1) > 1) and device.type == "cuda" and hasattr(frame_fn, "make_job"):
             top = _run_block_pipelined(frame_fn, lo, hi, block, device, inflight)
         else:
             top = torch.zeros((), dtype=torch.int64, device=device)
@@ -92,6 +92,8 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
     clustering on another stream BEFORE it waits for frame i's reads, so the GPU always has a second frame's kernels
     to fill the gaps.  One host thread; per-stream workspaces; per-frame RandomState, so the label maps do not depend
     on the interleaving.  Returns the largest label id seen (device scalar)."""
+    from . import _native
+    _native.lib().uoc_ms_set_stream_ordering(1 if depth > 1 else 0)   # persistent sampling grids: one at a time per device
     main = torch.cuda.current_stream(device)
     streams = _slot_streams(device, depth)
     for st in streams:
@@ -99,27 +101,31 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
     tops = [torch.zeros((), dtype=torch.int64, device=device) for _ in streams]
     pending = deque()
     nxt = lo
+    group = max(1, int(getattr(frame_fn, "frames_per_launch", 1)))
+    count = 0
 
     def issue_stage1(i):
-        slot = (i - lo) % depth
+        nonlocal count
+        slot = count % depth
+        count += 1
+        idx = list(range(i, min(i + group, hi)))
         with torch.cuda.stream(streams[slot]):
-            job = frame_fn.make_job(i)
+            job = frame_fn.make_job(idx)
             job.stage1()
-        return i, slot, job
+        return idx, slot, job
 
     while nxt < hi or pending:
         while nxt < hi and len(pending) < depth:
             pending.append(issue_stage1(nxt))
-            nxt += 1
-        i, slot, job = pending.popleft()
+            nxt += group
+        idx, slot, job = pending.popleft()
         with torch.cuda.stream(streams[slot]):
-            job.stage2()                          # blocks on this frame's ROI table only
-            job.stage3()                          # blocks on this frame's statistics; the other slots keep the GPU busy
-            labels, refined = job.result_device()
-            m = (refined if refined is not None else labels)[0]
-            tops[slot] = torch.maximum(tops[slot], m.max().to(torch.int64))
-            block[i - lo] = m.to(torch.uint8)
-        frame_fn.roi_counts.append(job.K)
+            job.stage2()                          # blocks on this job's ROI tables only
+            job.stage3()                          # blocks on this job's statistics; the other slots keep the GPU busy
+            for i, m in zip(idx, job.final_maps()):
+                tops[slot] = torch.maximum(tops[slot], m.max().to(torch.int64))
+                block[i - lo] = m.to(torch.uint8)
+        frame_fn.roi_counts.extend(job.K)
     for st in streams:
         main.wait_stream(st)
     return torch.stack(tops).max()
@@ -136,22 +142,25 @@ def _slot_streams(device, depth):
     return pool[:depth]
 
 
-def two_stage_frame_fn(samples, network, network_crop, first_index: int = 0):
+def two_stage_frame_fn(samples, network, network_crop, first_index: int = 0, frames_per_launch: Optional[int] = None):
     """frame_fn over pre-uploaded samples: final label map = refined map if stage 2 produced one,
     else the stage-1 map (what test_segnet stores as labels_refined, test_dataset.py:324-327).
-    Global frame i reads samples[(i - first_index) % len(samples)] (a rank passes the start of its block)."""
-    from .fcn.test_dataset import _run_frame, _check_clustering, DEPTH_FILTER, LAST_FRAME_STATS, FrameJob
+    Global frame i reads samples[(i - first_index) % len(samples)] (a rank passes the start of its block).
+    frames_per_launch (default $UOC_FRAMES_PER_LAUNCH or 3): frames the pipelined runner batches into one launch set
+    (fcn.test_dataset.FrameGroupJob)."""
+    from .fcn.test_dataset import _run_frame, _check_clustering, DEPTH_FILTER, LAST_FRAME_STATS, FrameGroupJob
 
     def fn(i: int) -> torch.Tensor:
         out, refined = _run_frame(samples[(i - first_index) % len(samples)], network, network_crop, DEPTH_FILTER, return_device=True)
         fn.roi_counts.append(LAST_FRAME_STATS["rois"])
         return (refined if refined is not None else out)[0]
 
-    def make_job(i: int):
-        """The same frame as a FrameJob for the pipelined runner, with its own RNG seeded from the global index."""
-        return FrameJob(samples[(i - first_index) % len(samples)], network, network_crop, DEPTH_FILTER,
-                        rng=np.random.RandomState(frame_rng_seed(i)))
+    def make_job(indices):
+        """The frames `indices` (global) as one FrameGroupJob, each with its own RNG seeded from its global index."""
+        return FrameGroupJob([samples[(i - first_index) % len(samples)] for i in indices], network, network_crop, DEPTH_FILTER,
+                             [np.random.RandomState(frame_rng_seed(i)) for i in indices])
     fn.make_job = make_job
+    fn.frames_per_launch = frames_per_launch if frames_per_launch is not None else int(os.environ.get("UOC_FRAMES_PER_LAUNCH", "3"))
     fn.roi_counts = []          # stage-1 ROIs per processed frame (the bench derives the algorithmic work from it)
     # every frame checks the clustering status once after stage 1 (a sticky device flag, so a stage-2 failure
     # surfaces at the next frame); fn.finish() is the check after the last frame
