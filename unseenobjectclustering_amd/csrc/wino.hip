@@ -190,8 +190,12 @@ __device__ __forceinline__ f32x4 wmfma(float a, float b, f32x4 c) {
 // the XCD mapping (0 %), and loading each wave's own U fragments straight into registers instead of through
 // LDS (-44 % DMA bytes, +0 %: the register loads cost what the DMA saved).  What is common to all of them is
 // the bytes a CU pulls out of L2 per MFMA (TCP_PENDING_STALL_CYCLES = 35 % of the kernel; the demand, 5.6 TB/s
-// chip-wide, is at the 6.4 TB/s MI355X_MICROARCH.md measures for LDS-DMA streams): only a larger block tile
-// would lower it, and at batch 1 there are not enough tiles for that.
+// chip-wide, is at the 6.4 TB/s MI355X_MICROARCH.md measures for LDS-DMA streams).
+// Round 2 tested that reading and it does NOT hold: a variant with a 128-channel block tile (all eight waves on one
+// frequency, BM + 128 rows per chunk: 10.4 instead of 14.4 B of operands per matrix-pipe cycle at TMT = 5, 8.6 at TMT = 7)
+// measured 573 vs 578 us on three frames of layer4 and 153 vs 168 us on layer3 — within noise — and was removed
+// again.  In-kernel counters (-DUOC_WINO_CLOCK): 2.33 GHz, 40.2 / 41.1 / 41.8 / 48.4 cycles per MFMA slot at
+// TMT 7 / 5 / 4 / 3 against 32, i.e. an overhead of ~240 + 97*TMT cycles per chunk and SIMD that scales WITH the tile.
 template <int TMT, int NSTG, int VARIANT = 0>
 __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
                                                         const float *__restrict__ bias_, const float *__restrict__ res_,
@@ -206,6 +210,9 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
   static_assert(SEG % 16 == 0 && NPASS <= 8 && NSTG >= 3 && NSTG <= 4, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef UOC_WINO_CLOCK
+  const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = wall_clock64();
+#endif
 
   const int total = G * ntiles * mtiles;
   const int per_xcd = (total + 7) >> 3;
@@ -367,6 +374,13 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
 #undef W_FRAG
 #undef W_MFMA_E
 
+#ifdef UOC_WINO_CLOCK
+  if (blockIdx.x == 8 && threadIdx.x == 0) {
+    const unsigned long long c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    printf("[wino clock] TMT %d nit %d: main loop %.1f us, %llu cycles -> %.0f MHz, %.1f cycles per MFMA slot (2 waves/SIMD x %d MFMAs per chunk)\n",
+           TMT, nit, (r1 - dbg_r0) / 100.0, c1 - dbg_c0, (c1 - dbg_c0) / ((r1 - dbg_r0) / 100.0), (double)(c1 - dbg_c0) / ((double)nit * 16 * TMT), 8 * TMT);
+  }
+#endif
   // ---- the two frequency groups meet in LDS; group 0 writes the 2x2 outputs ---------------------------
   f32x4 *red = reinterpret_cast<f32x4 *>(smem);  // [wn][k][i][lane]
   __syncthreads();
