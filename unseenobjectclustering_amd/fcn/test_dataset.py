@@ -324,7 +324,9 @@ class FrameJob:
         if "image_u8" in sample:  # raw uint8 / uint16 sample: input preparation runs on the device (io.prepare_on_device)
             from ..io import prepare_on_device
             sample = dict(sample, **prepare_on_device(sample, dev))
-        pin = lambda t: t.to(dev, non_blocking=True) if (not t.is_cuda and t.is_pinned()) else t.to(dev)
+        # non_blocking is a no-op for pageable host memory (the runtime stages it synchronously) and asynchronous for
+        # pinned memory; asking the tensor (`is_pinned()`) costs a driver query per call, so just always pass it
+        pin = lambda t: t.to(dev, non_blocking=True)
         self.image = image = pin(sample["image_color"]).float().contiguous()
         self.depth = depth = pin(sample["depth"]).float().contiguous() if uses_depth() else None     # :236-239
         if depth is None:
@@ -410,7 +412,9 @@ class FrameGroupJob:
         require_supported()
         dev = self.dev = _device()
         N = self.N
-        pin = lambda t: t.to(dev, non_blocking=True) if (not t.is_cuda and t.is_pinned()) else t.to(dev)
+        # non_blocking is a no-op for pageable host memory (the runtime stages it synchronously) and asynchronous for
+        # pinned memory; asking the tensor (`is_pinned()`) costs a driver query per call, so just always pass it
+        pin = lambda t: t.to(dev, non_blocking=True)
         images, depths = [], []
         for sm in self.samples:
             if "image_u8" in sm:
