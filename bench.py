@@ -452,9 +452,14 @@ def main():
             "roofline": roof, "frame_roofline": frame_roofline(rois, dt / K) if not stub else None,
             "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
         }
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
     if use_dist:
         dist.destroy_process_group()
+    if line is not None:
+        # last thing on stdout (RCCL writes a "Librccl path" banner to stdout while the process group is alive)
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
     return 0
 
 
