@@ -263,6 +263,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return relaunch_under_torchrun(args.gpus)
 
+    # ONE JSON line on stdout: libraries write to fd 1 too (RCCL prints a "Librccl path" banner), so the process's fd 1 is
+    # pointed at stderr for the whole run and the JSON line goes to a duplicate of the original stdout at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -459,7 +465,8 @@ def main():
     if line is not None:
         # last thing on stdout (RCCL writes a "Librccl path" banner to stdout while the process group is alive)
         sys.stdout.flush()
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
     return 0
 
 

@@ -108,7 +108,10 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
         nonlocal count
         slot = count % depth
         count += 1
-        idx = list(range(i, min(i + group, hi)))
+        n = min(group, hi - i)
+        if hasattr(frame_fn, "group_size"):
+            n = max(1, min(n, frame_fn.group_size(i, n)))   # only frames of one size share a launch set
+        idx = list(range(i, i + n))
         with torch.cuda.stream(streams[slot]):
             job = frame_fn.make_job(idx)
             job.stage1()
@@ -117,7 +120,7 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
     while nxt < hi or pending:
         while nxt < hi and len(pending) < depth:
             pending.append(issue_stage1(nxt))
-            nxt += group
+            nxt += len(pending[-1][0])
         idx, slot, job = pending.popleft()
         with torch.cuda.stream(streams[slot]):
             job.stage2()                          # blocks on this job's ROI tables only
@@ -159,7 +162,15 @@ def two_stage_frame_fn(samples, network, network_crop, first_index: int = 0, fra
         """The frames `indices` (global) as one FrameGroupJob, each with its own RNG seeded from its global index."""
         return FrameGroupJob([samples[(i - first_index) % len(samples)] for i in indices], network, network_crop, DEPTH_FILTER,
                              [np.random.RandomState(frame_rng_seed(i)) for i in indices])
+    def group_size(i: int, want: int) -> int:
+        """How many consecutive frames from global index i have frame i's image size (they are batched into one forward)."""
+        shape = lambda k: tuple(samples[(k - first_index) % len(samples)].get("image_color", samples[(k - first_index) % len(samples)].get("image_u8")).shape)
+        n = 1
+        while n < want and shape(i + n) == shape(i):
+            n += 1
+        return n
     fn.make_job = make_job
+    fn.group_size = group_size
     fn.frames_per_launch = frames_per_launch if frames_per_launch is not None else int(os.environ.get("UOC_FRAMES_PER_LAUNCH", "3"))
     fn.roi_counts = []          # stage-1 ROIs per processed frame (the bench derives the algorithmic work from it)
     # every frame checks the clustering status once after stage 1 (a sticky device flag, so a stage-2 failure
