@@ -196,6 +196,12 @@ __device__ __forceinline__ f32x4 wmfma(float a, float b, f32x4 c) {
 // measured 573 vs 578 us on three frames of layer4 and 153 vs 168 us on layer3 — within noise — and was removed
 // again.  In-kernel counters (-DUOC_WINO_CLOCK): 2.33 GHz, 40.2 / 41.1 / 41.8 / 48.4 cycles per MFMA slot at
 // TMT 7 / 5 / 4 / 3 against 32, i.e. an overhead of ~240 + 97*TMT cycles per chunk and SIMD that scales WITH the tile.
+// The part that scales is consistent with the 4 fragment reads per 16 MFMAs (a ds_read_b128 costs ~20-24 cycles of the
+// fp32 lanes, profiles/r02_mfma_microbenchmarks.md).  A register-blocked variant (wave tile 32 channels x 16*BT tiles,
+// waves of a frequency group 2 x 2: (2 + BT) / (8 BT) = 0.19 reads per MFMA at BT = 4 instead of 0.30) was built and
+// verified (all Winograd + network goldens) and measured 556 vs 574 us (three frames of layer4), 150 vs 162 us (three
+// frames of layer3) — 39.5 cycles per MFMA slot — but 5-40 % slower on every shape whose tile count does not fill
+// whole rounds of its fixed 64 / 96 / 128-tile blocks; ~1 % of a frame, not kept (scripts/wino2_bench.py has the table).
 template <int TMT, int NSTG, int VARIANT = 0>
 __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
                                                         const float *__restrict__ bias_, const float *__restrict__ res_,
