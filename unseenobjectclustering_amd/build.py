@@ -36,18 +36,24 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libuoc_hip.so")
-    objs = []
+    objs, jobs = [], []
     os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h"))
+    newest_header = max([os.path.getmtime(h) for h in headers], default=0.0)
     for src in sources():
         obj = os.path.join(CSRC, "build", os.path.basename(src)[:-4] + ".o")
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(
-                os.path.getmtime(src), *[os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, "*.h"))],
-                *[os.path.getmtime(h) for h in glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h"))]):
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+        objs.append(obj)
+    if jobs:      # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
-        objs.append(obj)
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
+            list(pool.map(run, jobs))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
