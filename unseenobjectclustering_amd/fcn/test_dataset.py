@@ -494,6 +494,15 @@ class FrameGroupJob:
             self.refined[f] = refined.view(H, W)
         self.labels_crop = self.image = self.depth = None
 
+    def pending_event(self, state):
+        """The event of the device->host read the next stage waits for (state 1: ROI tables, 2: match statistics), or
+        None if that stage has nothing to wait for."""
+        if self.network_crop is None:
+            return None
+        if state == 1:
+            return self.host.table_ready
+        return self.host.stats_ready if sum(self.K) > 0 else None
+
     def final_maps(self):
         """Per frame: the refined map if stage 2 produced one, else the stage-1 map ([H,W] int32, device)."""
         return [self.refined[f] if self.refined[f] is not None else self.labels[f].view(self.H, self.W) for f in range(self.N)]

@@ -42,7 +42,7 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     label id that does not fit uint8) must not leave the others waiting in the collective, so every rank
     first all-reduces an error flag and ALL ranks raise when any rank failed.
 
-    `inflight` (default: $UOC_FRAMES_IN_FLIGHT or 2): when frame_fn offers `make_job` (two_stage_frame_fn does), that
+    `inflight` (default: $UOC_FRAMES_IN_FLIGHT or 3): when frame_fn offers `make_job` (two_stage_frame_fn does), that
     many frames are kept in flight on this GPU, each on its own stream (_run_block_pipelined); 1 = one frame at a
     time on the current stream.  The label maps are the same either way."""
     per = (num_frames + world - 1) // world
@@ -51,7 +51,7 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     collective = gather and (world > 1 or force_collective)
     error = None
     if inflight is None:
-        inflight = int(os.environ.get("UOC_FRAMES_IN_FLIGHT", "2"))
+        inflight = int(os.environ.get("UOC_FRAMES_IN_FLIGHT", "3"))
     try:
         if (inflight > 1 or getattr(frame_fn, "frames_per_launch", 1) > 1) and device.type == "cuda" and hasattr(frame_fn, "make_job"):
             top = _run_block_pipelined(frame_fn, lo, hi, block, device, inflight)
@@ -84,14 +84,16 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
 
 
 def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device: torch.device, depth: int):
-    """Frames lo..hi-1 of this rank with `depth` of them in flight, one stream per slot (fcn.test_dataset.FrameJob).
+    """Frames lo..hi-1 of this rank on `depth` streams, each stream working on one job (fcn.test_dataset.FrameGroupJob:
+    `frames_per_launch` frames batched into one set of launches per stage).
 
-    A frame has two points where the host needs a few bytes from the device (ROI count; crop keep table + ROI order).
+    A job has two points where the host needs a few bytes from the device (ROI counts; crop keep tables + ROI order).
     With one frame at a time the matrix pipes idle through those reads and through the latency-bound kernels around
-    them (farthest-point sampling 2 x 0.5 ms, seed components, glue).  Here the host queues frame i+1's embedding +
-    clustering on another stream BEFORE it waits for frame i's reads, so the GPU always has a second frame's kernels
-    to fill the gaps.  One host thread; per-stream workspaces; per-frame RandomState, so the label maps do not depend
-    on the interleaving.  Returns the largest label id seen (device scalar)."""
+    them (farthest-point sampling 2 x 0.5 ms, seed components, glue).  Here every job runs on its own stream and the
+    host, a single thread, is event-driven: it queues the next stage of whichever job's read has landed and never waits
+    on one job while another could be fed, so the GPU always has other jobs' kernels to fill the gaps.  Per-stream
+    workspaces; per-frame RandomState, so the label maps do not depend on the interleaving.  Returns the largest label
+    id seen (device scalar)."""
     from . import _native
     _native.lib().uoc_ms_set_stream_ordering(1 if depth > 1 else 0)   # persistent sampling grids: one at a time per device
     main = torch.cuda.current_stream(device)
@@ -99,15 +101,13 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
     for st in streams:
         st.wait_stream(main)                      # inputs / weights were produced on the caller's stream
     tops = [torch.zeros((), dtype=torch.int64, device=device) for _ in streams]
-    pending = deque()
     nxt = lo
     group = max(1, int(getattr(frame_fn, "frames_per_launch", 1)))
-    count = 0
+    poll = os.environ.get("UOC_PIPE_POLL", "1") != "0"
+    slots = [None] * depth          # per stream: None or [idx, job, state]; state 1 = waits for the tables, 2 = for the statistics
+    done_counts = {}
 
-    def issue_stage1(i):
-        nonlocal count
-        slot = count % depth
-        count += 1
+    def issue_stage1(slot, i):
         n = min(group, hi - i)
         if hasattr(frame_fn, "group_size"):
             n = max(1, min(n, frame_fn.group_size(i, n)))   # only frames of one size share a launch set
@@ -115,20 +115,52 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
         with torch.cuda.stream(streams[slot]):
             job = frame_fn.make_job(idx)
             job.stage1()
-        return idx, slot, job
+        slots[slot] = [idx, job, 1]
+        return n
 
-    while nxt < hi or pending:
-        while nxt < hi and len(pending) < depth:
-            pending.append(issue_stage1(nxt))
-            nxt += len(pending[-1][0])
-        idx, slot, job = pending.popleft()
+    def advance(slot, block_host):
+        """Moves the slot's job one stage on if its pending device->host read has completed (or, with block_host, waits
+        for it).  Returns True if something was issued."""
+        idx, job, state = slots[slot]
+        ev = job.pending_event(state)
+        if ev is not None and not block_host and not ev.query():
+            return False
         with torch.cuda.stream(streams[slot]):
-            job.stage2()                          # blocks on this job's ROI tables only
-            job.stage3()                          # blocks on this job's statistics; the other slots keep the GPU busy
+            if state == 1:
+                job.stage2()
+                slots[slot][2] = 2
+                return True
+            job.stage3()
             for i, m in zip(idx, job.final_maps()):
                 tops[slot] = torch.maximum(tops[slot], m.max().to(torch.int64))
                 block[i - lo] = m.to(torch.uint8)
-        frame_fn.roi_counts.extend(job.K)
+        done_counts[idx[0]] = list(job.K)
+        slots[slot] = None
+        return True
+
+    # Event-driven: the host never waits on one job while another stream has a stage that could be queued.  Each job
+    # is advanced as soon as its small device->host read has landed (Event.query, non-blocking); only when nothing is
+    # ready does the host wait — on the oldest job.  With UOC_PIPE_POLL=0 the host walks the jobs strictly in order.
+    order = deque()
+    while nxt < hi or any(s is not None for s in slots):
+        progressed = False
+        for slot in range(depth):
+            if slots[slot] is None and nxt < hi:
+                nxt += issue_stage1(slot, nxt)
+                order.append(slot)
+                progressed = True
+        for slot in list(order):
+            if slots[slot] is not None and poll and advance(slot, False):
+                progressed = True
+                if slots[slot] is None:
+                    order.remove(slot)
+        if not progressed and order:
+            slot = order[0]
+            advance(slot, True)
+            if slots[slot] is None:
+                order.popleft()
+    for k in sorted(done_counts):
+        frame_fn.roi_counts.extend(done_counts[k])
     for st in streams:
         main.wait_stream(st)
     return torch.stack(tops).max()
