@@ -1,3 +1,12 @@
+"""Dev helper: which call makes `rocprofv3 --kernel-trace -- python ...` segfault at process exit?
+
+    rocprofv3 --kernel-trace -d /tmp/x -o t -- python scripts/rocprof_exit_bisect.py load|fps|hc|cluster
+
+Finding (round 2, ROCm 7.2): any process that launched the persistent (cooperative or plain) farthest-point sampling
+kernel crashes inside the tool's exit handler — also with round 1's library, with or without the stream-ordering
+event, with or without dynamic LDS; the streaming sampling kernel (UOC_FPS_PERSISTENT=0) does not.  The trace database
+IS written when the interpreter falls off the end of the script (bench.py therefore does not call sys.exit(0)); with
+SystemExit -> Py_Exit the crash comes first and the database is lost."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
