@@ -231,14 +231,10 @@ __device__ float4 g_zero_page[8];  // zero-initialised device memory
 // One LDS-DMA: 64 lanes x 16 B land at LDS byte address `lds_dst` (wave-uniform) + 16*lane.  Written
 // as inline asm so that hipcc does not count it: with the builtin, the compiler drains the DMA queue
 // (s_waitcnt vmcnt(0)) in front of every ds_read; here the counted waits below are the only ones.
-// M0 carries the LDS base and is compiler-reserved, hence saved/restored inside the statement.
+// M0 carries the LDS base.  It is written without save / restore (two scalar moves per DMA less; see wglds16s in
+// wino.hip): nothing else in these kernels lives in m0 and hipcc sets it itself right before any use of its own.
 __device__ __forceinline__ void glds16(const float *g, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(g), "s"(lds_dst)
-      : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_dst) : "memory");
 }
 
 template <int N>

@@ -155,23 +155,14 @@ __constant__ float c_wino_y[16][4] = {
     {0, 0, -1, 0}, {0, 0, -1, -1}, {0, 0, -1, 1},  {0, 0, 0, 1},    // i = 3
 };
 
-__device__ __forceinline__ void wglds16(const float *g, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(g), "s"(lds_dst)
-      : "memory");
-}
-// the same with the address split into a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset:
+// one LDS-DMA (see glds16 in conv.hip) with the address split into a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset:
 // no VALU instruction per load (MFMA issue shares its port with the VALU: scripts/mfma_patterns.hip)
 __device__ __forceinline__ void wglds16s(const float *base, unsigned voff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(base), "s"(lds_dst)
-      : "memory");
+  // m0 is written without being saved / restored (two scalar moves per DMA less: scalar instructions in a wave's stream
+  // delay its MFMA issue like everything else).  Nothing else in these kernels lives in m0 — gfx9+ LDS instructions do
+  // not read it and hipcc sets it itself right before any use of its own (movrel, sendmsg); declaring it clobbered makes
+  // hipcc wrap the statement in the very save / restore this avoids.
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void wwait_vmcnt() {
@@ -266,23 +257,24 @@ __global__ __launch_bounds__(512) void wino_gemm_kernel(const float *__restrict_
       d_off[j] = (unsigned)((tau * WBK + 4 * c) * sizeof(float));
     }
   }
-  // running (frequency-pair e, cin chunk cc) of the chunk being issued
-  int q_e = 0, q_cc = 0;
+  // Row base of every DMA pass for the chunk being issued.  Chunk index = (g*16 + frequency)*cpt + cin chunk runs
+  // contiguously through a frequency group's 8 frequencies, so each pass keeps ONE wave-uniform 64-bit pointer (U or V
+  // plane of its frequency group) and advances it by one chunk per issue: NISS scalar 64-bit adds instead of
+  // re-deriving four bases and selecting among them (the loop had ~100 SALU per chunk).
+  const float *q_ptr[NISS];
+  size_t q_step[NISS];
+#pragma unroll
+  for (int j = 0; j < NISS; ++j) {
+    const int kd = d_kind[j];
+    const size_t step = (kd & 1) ? (size_t)Cout * WBK : (size_t)NT * WBK;
+    q_step[j] = VARIANT == 4 ? 0 : step;
+    q_ptr[j] = ((kd & 1) ? U : V) + ((size_t)g * 16 + ((kd & 2) ? 8 : 0)) * cpt * step;
+  }
 #define W_ISSUE(STG)                                                                                    \
   {                                                                                                     \
-    /* four wave-uniform row bases (U / V plane of each frequency group) for this chunk; the per-lane  \
-       part of an address is a select + a 32-bit offset add */                                          \
-    const size_t ch0_ = VARIANT == 4 ? 0 : (size_t)(g * 16 + q_e) * cpt + q_cc, ch1_ = ch0_ + 8 * cpt;  \
-    const float *bu0_ = U + ch0_ * Cout * WBK, *bu1_ = U + ch1_ * Cout * WBK;                           \
-    const float *bv0_ = V + ch0_ * NT * WBK, *bv1_ = V + ch1_ * NT * WBK;                               \
     _Pragma("unroll") for (int j = 0; j < NISS; ++j) {                                                  \
-      const int kd = d_kind[j];                                                                         \
-      const float *b_ = (kd & 1) ? ((kd & 2) ? bu1_ : bu0_) : ((kd & 2) ? bv1_ : bv0_);                 \
-      wglds16s(b_, d_off[j], lds_base + (unsigned)(((STG)*STAGE + d_r0[j] * WBK) * sizeof(float)));     \
-    }                                                                                                   \
-    if (++q_cc == cpt) {                                                                                \
-      q_cc = 0;                                                                                         \
-      ++q_e;                                                                                            \
+      wglds16s(q_ptr[j], d_off[j], lds_base + (unsigned)(((STG)*STAGE + d_r0[j] * WBK) * sizeof(float))); \
+      q_ptr[j] += q_step[j];                                                                            \
     }                                                                                                   \
   }
   // before the barrier of step `it`: chunk it+1 must have landed; younger chunks (up to NSTG-2 of them) may fly
