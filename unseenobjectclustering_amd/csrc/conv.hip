@@ -242,6 +242,28 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// The same through a raw buffer descriptor: address = descriptor base + soff (wave-uniform SGPR) + voff (per lane);
+// a lane whose voff lies beyond the descriptor's num_records delivers ZEROS (raw-buffer range check; soff is not part
+// of it).  That is the whole per-lane address arithmetic of an implicit-GEMM chunk: the (tap, cin-slice) offset is
+// one scalar, the pixel's offset a loop-invariant VGPR, an out-of-image tap the out-of-range constant.
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobVoff = 0xFFFFFFF0u;
+__device__ __forceinline__ void blds16(v4i srd, unsigned voff, unsigned soff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :
+               : "v"(voff), "s"(srd), "s"(soff), "s"(lds_dst)
+               : "memory");
+}
+__device__ __forceinline__ v4i make_srd(const void *base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  v4i r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+  r.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));   // stride 0, no swizzle
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = 0x00020000;
+  return r;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, int VARIANT = 0>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvParams p, int ntiles, int mtiles) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -314,6 +336,69 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
     }
   }
 
+  // ---- non-stem layers: buffer-descriptor DMA (blds16).  Passes are split by KIND at compile time: NPA passes over the
+  // BM activation rows, then NPW passes over the BN weight rows (same total as NPASS for every tile family); a pass
+  // whose rows would start beyond its kind's range re-copies the kind's last 8 rows (identical bytes). ----
+  constexpr int NPA = (BM + RPP - 1) / RPP, NPW = (BN + RPP - 1) / RPP;
+  static_assert(STEM || NPA + NPW == NPASS, "pass split");
+  const unsigned bias_bytes = (unsigned)((p.pad * p.W + p.pad) * p.Cin) * 4u;   // most negative pixel offset
+  const v4i srd_a = make_srd(reinterpret_cast<const char *>(in) - bias_bytes,
+                             (unsigned)((size_t)p.B * p.H * p.W * p.Cin * 4) + bias_bytes);
+  const v4i srd_w = make_srd(w, (unsigned)((size_t)T * p.Cout * Kc * 4));
+  int l_r0[NPASS];          // first row of the wave's 8-row group in the stage
+  unsigned l_voff[NPASS];   // per-lane byte offset (activations: bias + image base + (iy0*W + ix0)*Cin + 4c)
+  unsigned l_mask[NPASS];   // activations: bit `tap` set if that tap lies inside the image for the lane's pixel
+  if (!STEM) {
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+      const bool isw = j >= NPA;
+      int r0 = (isw ? BM + (j - NPA) * RPP : j * RPP) + wave * 8;
+      if (!isw && r0 >= BM) r0 = BM - 8;
+      if (isw && r0 >= R) r0 = R - 8;
+      l_r0[j] = r0;
+      const int r = r0 + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      l_mask[j] = 0;
+      l_voff[j] = kOobVoff;
+      if (isw) {
+        l_voff[j] = (unsigned)(((n0 + (r - BM)) * Kc + 4 * c) * 4);
+      } else {
+        const int m = m0 + r;
+        if (m < M) {
+          const int b = m / HoWo;
+          const int rr = m - b * HoWo;
+          const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+          const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+          l_voff[j] = bias_bytes + (unsigned)((b * p.H * p.W * p.Cin + (iy0 * p.W + ix0) * p.Cin + 4 * c) * 4);
+          unsigned mk = 0, bit = 1;
+          for (int kh = 0, iy = iy0; kh < p.KH; ++kh, iy += p.dil) {
+            const bool oky = (unsigned)iy < (unsigned)p.H;
+            for (int kw = 0, ix = ix0; kw < p.KW; ++kw, ix += p.dil, bit <<= 1)
+              if (oky && (unsigned)ix < (unsigned)p.W) mk |= bit;
+          }
+          l_mask[j] = mk;
+        }
+      }
+    }
+  }
+  // one chunk of the lean path: two scalars (activation / weight offset of the chunk), per activation pass a bit test
+  // and a select, per DMA the LDS destination
+#define UOC_ISSUE_LEAN(STG)                                                                                    \
+  {                                                                                                            \
+    const unsigned soff_a_ = (unsigned)__builtin_amdgcn_readfirstlane(                                         \
+        ((q_kh * p.dil * p.W + q_kw * p.dil) * p.Cin + q_c0) * 4);                                             \
+    const unsigned soff_w_ = (unsigned)__builtin_amdgcn_readfirstlane((q_tap * p.Cout * Kc + q_c0) * 4);       \
+    _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                                        \
+      const unsigned dst_ = lds_base + (unsigned)(((STG)*STAGE + l_r0[j] * BK) * sizeof(float));               \
+      if (j < NPA) {                                                                                           \
+        const unsigned v_ = ((l_mask[j] >> q_tap) & 1u) ? l_voff[j] : kOobVoff;                                \
+        blds16(srd_a, v_, soff_a_, dst_);                                                                      \
+      } else {                                                                                                 \
+        blds16(srd_w, l_voff[j], soff_w_, dst_);                                                               \
+      }                                                                                                        \
+    }                                                                                                          \
+  }
+
 #define UOC_ISSUE_ONE(KN, STG, J)                                                                              \
   if ((J) < NPASS) {                                                                                           \
     const int j = (J) < NPASS ? (J) : 0;                                                                       \
@@ -334,8 +419,10 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
   }
 #define UOC_ISSUE(KN, STG)                                                                                     \
   {                                                                                                            \
-    UOC_ISSUE_ONE(KN, STG, 0) UOC_ISSUE_ONE(KN, STG, 1) UOC_ISSUE_ONE(KN, STG, 2) UOC_ISSUE_ONE(KN, STG, 3)    \
-    UOC_ISSUE_ONE(KN, STG, 4) UOC_ISSUE_ONE(KN, STG, 5) UOC_ISSUE_ONE(KN, STG, 6) UOC_ISSUE_ONE(KN, STG, 7)    \
+    if (!STEM) UOC_ISSUE_LEAN(STG) else {                                                                      \
+      UOC_ISSUE_ONE(KN, STG, 0) UOC_ISSUE_ONE(KN, STG, 1) UOC_ISSUE_ONE(KN, STG, 2) UOC_ISSUE_ONE(KN, STG, 3)  \
+      UOC_ISSUE_ONE(KN, STG, 4) UOC_ISSUE_ONE(KN, STG, 5) UOC_ISSUE_ONE(KN, STG, 6) UOC_ISSUE_ONE(KN, STG, 7)  \
+    }                                                                                                          \
   }
 #define UOC_FRAG2(STG, HH, WA, XB)                                                                           \
   {                                                                                                          \
@@ -436,6 +523,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
   }
 #undef UOC_ADVANCE
 #undef UOC_ISSUE
+#undef UOC_ISSUE_LEAN
 #undef UOC_ISSUE_ONE
 #undef UOC_FRAG2
 #undef UOC_MFMA_E
@@ -758,6 +846,8 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     return launch_cfg<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
   }
   UOC_REQUIRE(p.Cin % BK == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, BK);
+  UOC_REQUIRE((size_t)p.B * p.H * p.W * p.Cin * 4 + (size_t)(p.pad * p.W + p.pad) * p.Cin * 4 < (1ull << 31),
+              "conv: a group's input exceeds the 2 GB a 32-bit buffer offset addresses");
   UOC_REQUIRE(p.Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", p.Cout);
   static int variant = -1;
   if (variant < 0) {
