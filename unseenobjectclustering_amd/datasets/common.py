@@ -2,10 +2,14 @@
 BGR image -> network input, indexed-PNG labels -> {0..K-1}, organised point cloud -> XYZ image."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
+import torch.utils.data as data
 
 from ..fcn.config import cfg
+from .imdb import imdb
 from .pcd import load_xyz
 
 
@@ -47,3 +51,47 @@ def xyz_blob(pcd_filename, height, width):
 
 def pixel_mean():
     return torch.tensor(cfg.PIXEL_MEANS / 255.0).float()
+
+
+class SceneDataset(data.Dataset, imdb):
+    """What OCID and OSD share (ocid_object.py:69-112, osd_object.py:61-100): a list of colour images; per item the
+    network-input colour blobs, the compacted foreground labels, the path relative to the dataset root and — for
+    DEPTH / RGBD input — the organised cloud as an XYZ image.  Subclasses say where things are (`_label_file`,
+    `_cloud_file`), which ids are background (`_drop_background`) and what the root marker in a path is (`_marker`)."""
+
+    _marker = ""
+    _width, _height = 640, 480
+
+    def _setup(self, name, root, image_files):
+        imdb.__init__(self)
+        self._name = name
+        self._root = root
+        self._classes_all = ("__background__", "foreground")
+        self._classes = self._classes_all
+        self._pixel_mean = pixel_mean()
+        self._files = [str(f) for f in image_files]
+        print("%d images for dataset %s" % (len(self._files), self._name))
+        self._size = len(self._files)
+        assert os.path.exists(root), "{} path does not exist: {}".format(name.rsplit("_", 1)[0], root)
+
+    process_label = staticmethod(process_label)
+
+    def _drop_background(self, labels, labels_filename):
+        return labels
+
+    def __getitem__(self, idx):
+        if cfg.MODE == "TRAIN":
+            raise NotImplementedError("training-time augmentation is out of scope (inference / evaluation only)")
+        filename = self._files[idx]
+        image_blob, bgr_blob = image_blobs(imread_bgr(filename), self._pixel_mean)
+        labels_filename = self._label_file(filename)
+        labels = self._drop_background(imread_indexed(labels_filename), labels_filename)
+        cut = filename.find(self._marker) + len(self._marker) + 1
+        sample = {"image_color": image_blob, "image_color_bgr": bgr_blob,
+                  "label": torch.from_numpy(self.process_label(labels)).unsqueeze(0), "filename": filename[cut:]}
+        if cfg.INPUT in ("DEPTH", "RGBD"):
+            sample["depth"] = xyz_blob(self._cloud_file(filename), self._height, self._width)
+        return sample
+
+    def __len__(self):
+        return self._size
