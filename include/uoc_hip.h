@@ -70,6 +70,14 @@ size_t uoc_ms_workspace_bytes(int batch, int n, int m);
 int uoc_ms_select_seeds(const float *d_X, int batch, int n, int m, const int32_t *d_first_index,
                         float *d_seeds, int32_t *d_indices, void *d_ws, size_t ws_bytes, void *stream);
 
+/* The same with the first num_init rows of every d_seeds[b] already chosen by the caller — the init_seeds /
+ * num_init_seeds continuation of select_smart_seeds, mean_shift.py:142-170 (`seeds = init_seeds` there too: the
+ * selection is written into the caller's matrix).  The given rows need not be rows of X; their d_indices stay -1
+ * like the reference's selected_indices.  num_init = 0 is uoc_ms_select_seeds (d_first_index is then required;
+ * otherwise it is not read).  num_init > 0 always runs the one-launch-per-step kernel. */
+int uoc_ms_select_seeds_from(const float *d_X, int batch, int n, int m, int num_init, const int32_t *d_first_index,
+                             float *d_seeds, int32_t *d_indices, void *d_ws, size_t ws_bytes, void *stream);
+
 /* iters x { W = exp(kappa Z X^T); Z = normalize(W X) } — seed_hill_climbing_ball,
  * mean_shift.py:79-109 with ball_kernel :26.  d_Z [batch][m][64] is updated in place. */
 int uoc_ms_hill_climb(const float *d_X, int batch, int n, float *d_Z, int m, float kappa, int iters,

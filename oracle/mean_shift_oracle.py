@@ -24,22 +24,32 @@ def cosine_distance_to(X: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     return 0.5 * (1 - torch.mm(X, v.unsqueeze(1))[:, 0])
 
 
-def select_seeds(X: torch.Tensor, num_seeds: int, first_index: int):
+def select_seeds(X: torch.Tensor, num_seeds: int, first_index, init_seeds: torch.Tensor = None, num_init_seeds: int = 0):
     """Farthest-point seed selection in cosine distance (mean_shift.py:128-189).
 
     The reference draws ``first_index`` from the global NumPy RNG (:155); here it is an
     argument.  The reference keeps a [n, num_seeds] distance matrix and re-reduces
     ``min(distances[:, :i])`` each step (:174); a running minimum is the same value
     bit for bit (min is exact), so that is what is kept here.
+    With ``init_seeds`` [num_seeds, d] the first ``num_init_seeds`` rows are taken as chosen (:142-170): their
+    distances enter the minimum, their indices stay -1, no first index is used unless num_init_seeds == 0.
     Returns (seeds [m,d], indices [m] int64).
     """
     n, d = X.shape
     idx = torch.full((num_seeds,), -1, dtype=torch.long)
-    seeds = torch.empty((num_seeds, d), dtype=X.dtype)
-    idx[0] = int(first_index)
-    seeds[0] = X[int(first_index)]
-    dmin = cosine_distance_to(X, seeds[0])
-    for i in range(1, num_seeds):
+    if init_seeds is None or num_init_seeds == 0:
+        seeds = torch.empty((num_seeds, d), dtype=X.dtype) if init_seeds is None else init_seeds.clone()
+        idx[0] = int(first_index)
+        seeds[0] = X[int(first_index)]
+        dmin = cosine_distance_to(X, seeds[0])
+        start = 1
+    else:
+        seeds = init_seeds.clone()
+        dmin = cosine_distance_to(X, seeds[0])
+        for i in range(1, num_init_seeds):
+            dmin = torch.minimum(dmin, cosine_distance_to(X, seeds[i]))          # :165-170
+        start = num_init_seeds
+    for i in range(start, num_seeds):
         j = torch.argmax(dmin)                       # :175 (first maximal index)
         idx[i] = j
         seeds[i] = X[j]

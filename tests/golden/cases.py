@@ -17,6 +17,17 @@ KAPPA = 20.0
 EPSILON = 0.04
 RNG_SEED = 3
 
+# select_smart_seeds(init_seeds=..., num_init_seeds=k) (mean_shift.py:142-170).  init: 'rows' = the first k seeds of a
+# plain selection on the same field (a continued selection), 'free' = k unit vectors that are not rows of X,
+# 'empty' = an init matrix with num_init_seeds = 0 (the first seed is then drawn from the RNG as usual)
+SEED_CONTINUATION_CASES = {
+    "cont_rows_60x80":   dict(seed=21, H=60,  W=80,  num_objects=4, noise=0.05, m=30,  k=6,  init="rows"),
+    "cont_free_96x128":  dict(seed=22, H=96,  W=128, num_objects=5, noise=0.05, m=40,  k=5,  init="free"),
+    "cont_free_224":     dict(seed=23, H=224, W=224, num_objects=6, noise=0.08, m=100, k=17, init="free"),
+    "cont_empty_37x53":  dict(seed=24, H=37,  W=53,  num_objects=3, noise=0.05, m=20,  k=0,  init="empty"),
+    "cont_all_given":    dict(seed=25, H=37,  W=53,  num_objects=3, noise=0.05, m=8,   k=8,  init="free"),
+}
+
 
 # ---------------------------------------------------------------------------------------------
 # Shared input builders (used by make_golden.py in the build container AND by the tests).
@@ -25,6 +36,16 @@ import numpy as np
 import torch
 
 from unseenobjectclustering_amd import synth
+
+
+def continuation_inputs(c):
+    """X [n,64] and the init_seeds [m,64] matrix (rows >= k are NaN-free filler the selection overwrites) of a
+    SEED_CONTINUATION_CASES entry; for 'rows' the caller fills the first k rows from a plain selection."""
+    X, _ = synth.embedding_field(c["seed"], c["H"], c["W"], 64, c["num_objects"], c["noise"])
+    rng = np.random.default_rng(1000 + c["seed"])
+    init = rng.standard_normal((c["m"], 64)).astype(np.float32)
+    init /= np.linalg.norm(init, axis=1, keepdims=True)
+    return X, init
 
 
 def sample_positions(seed, n, count):

@@ -4,7 +4,7 @@ Imports the reference's own Python (through tests/golden/ref_harness.py) and rec
 outputs on repo-owned synthetic inputs.  The .npz files written next to this script are the
 fixtures tests/ compares the oracle (CPU) and the HIP path (GPU) against.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [meanshift|glue|backbone|e2e|demo|modes|evaluation|prep|segnet|all]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [meanshift|seedcont|glue|backbone|e2e|demo|modes|evaluation|prep|segnet|all]
 """
 from __future__ import annotations
 
@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
 import ref_harness  # noqa: E402
-from cases import (MEANSHIFT_CASES, KAPPA, EPSILON, RNG_SEED, BACKBONE_CASES, GLUE_CASES, E2E_CASES,  # noqa: E402
+from cases import (SEED_CONTINUATION_CASES, continuation_inputs, MEANSHIFT_CASES, KAPPA, EPSILON, RNG_SEED, BACKBONE_CASES, GLUE_CASES, E2E_CASES,  # noqa: E402
                    MODES, MODE_BACKBONE_CASES, MODE_GLUE_CASES, MODE_E2E_CASES, WIDE_MEANSHIFT_CASES,
                    EVAL_CASES, eval_pair, munkres_cases, PREP_SYNTH, prep_synthetic_arrays, SEGNET_RUNS, SegnetLoader,
                    segnet_samples, segnet_stub_networks, SEGNET_METRIC_KEYS,
@@ -51,6 +51,32 @@ def make_meanshift(ref):
         out[name + "/seed_labels"] = seed_labels.numpy().astype(np.int32)
         print(name, "clusters:", np.unique(out[name + "/labels"]).tolist(), "first idx", int(idx[0]), flush=True)
     np.savez_compressed(os.path.join(HERE, "meanshift.npz"), **out)
+
+
+def make_seedcont(ref):
+    """select_smart_seeds with init_seeds / num_init_seeds, the reference's own code (mean_shift.py:142-170)."""
+    ms = ref.mean_shift
+    out = {}
+    for name, c in SEED_CONTINUATION_CASES.items():
+        X, init = continuation_inputs(c)
+        Xt, it = torch.from_numpy(X), torch.from_numpy(init.copy())
+        if c["init"] == "rows":
+            np.random.seed(RNG_SEED)
+            plain, pidx = ms.select_smart_seeds(Xt, c["m"], return_selected_indices=True, metric="cosine")
+            it[:c["k"]] = plain[:c["k"]]
+            out[name + "/plain_indices"] = pidx.numpy().astype(np.int32)
+        np.random.seed(RNG_SEED)
+        seeds, idx = ms.select_smart_seeds(Xt, c["m"], return_selected_indices=True, init_seeds=it,
+                                           num_init_seeds=c["k"], metric="cosine")
+        assert seeds.data_ptr() == it.data_ptr()                       # the reference selects in place
+        out[name + "/rng_draws"] = np.int32(0 if c["k"] else 1)
+        out[name + "/next_rng"] = np.int64(np.random.randint(0, 1 << 30))   # where the global RNG stands afterwards
+        out[name + "/indices"] = idx.numpy().astype(np.int32)
+        out[name + "/seeds"] = seeds.numpy().astype(np.float32)
+        if c["init"] == "rows":
+            assert np.array_equal(out[name + "/indices"][c["k"]:], out[name + "/plain_indices"][c["k"]:])
+        print(name, "indices", out[name + "/indices"][:10].tolist(), flush=True)
+    np.savez_compressed(os.path.join(HERE, "seedcont.npz"), **out)
 
 
 def make_backbone(ref):
@@ -395,6 +421,8 @@ def main():
     torch.manual_seed(0)
     if what in ("meanshift", "all"):
         make_meanshift(ref)
+    if what in ("seedcont", "all"):
+        make_seedcont(ref)
     if what in ("backbone", "all"):
         make_backbone(ref)
     if what in ("glue", "all"):

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from oracle import mean_shift_oracle as O
-from tests.golden.cases import MEANSHIFT_CASES, KAPPA, EPSILON
+from tests.golden.cases import MEANSHIFT_CASES, KAPPA, EPSILON, SEED_CONTINUATION_CASES, continuation_inputs
 from unseenobjectclustering_amd import synth
 from unseenobjectclustering_amd.utils import mean_shift as MS
 
@@ -68,6 +68,43 @@ def test_stagewise_vs_oracle(golden, device, name):
     sl_o = O.seed_connected_components(Z_o, EPSILON)
     sl = MS.connected_components(Z_o.to(device), EPSILON)
     assert torch.equal(sl, sl_o)
+
+
+@pytest.mark.parametrize("name", list(SEED_CONTINUATION_CASES))
+def test_seed_continuation_matches_reference_golden(golden_dir, device, name):
+    """select_smart_seeds(init_seeds=..., num_init_seeds=k) (mean_shift.py:142-170) through uoc_ms_select_seeds_from:
+    indices (-1 for the given rows) and the seed matrix bit-exact against the reference's run; the selection lands in
+    the caller's init_seeds tensor; the global RNG is consumed only when k == 0."""
+    g = np.load(os.path.join(golden_dir, "seedcont.npz"))
+    c = SEED_CONTINUATION_CASES[name]
+    X, init = continuation_inputs(c)
+    Xd, it = torch.from_numpy(X).to(device), torch.from_numpy(init).to(device)
+    if c["init"] == "rows":
+        np.random.seed(3)
+        plain, pidx = MS.select_smart_seeds(Xd, c["m"], return_selected_indices=True)
+        assert np.array_equal(pidx.numpy().astype(np.int32), g[name + "/plain_indices"])
+        it[:c["k"]] = plain[:c["k"]]
+    np.random.seed(3)
+    seeds, idx = MS.select_smart_seeds(Xd, c["m"], return_selected_indices=True, init_seeds=it, num_init_seeds=c["k"])
+    assert seeds.data_ptr() == it.data_ptr()
+    assert idx.dtype == torch.int64 and np.array_equal(idx.numpy().astype(np.int32), g[name + "/indices"])
+    assert np.array_equal(seeds.cpu().numpy(), g[name + "/seeds"])
+    assert int(np.random.randint(0, 1 << 30)) == int(g[name + "/next_rng"])
+    (only_seeds,) = MS.select_smart_seeds(Xd, c["m"], init_seeds=it.clone(), num_init_seeds=c["m"])   # nothing left to pick
+    assert torch.equal(only_seeds, it)
+
+
+def test_seed_continuation_argument_errors(device):
+    Xd = torch.from_numpy(synth.embedding_field(1, 16, 16, 64, 2, 0.05)[0]).to(device)
+    good = torch.zeros((10, 64), device=device)
+    with pytest.raises(TypeError):
+        MS.select_smart_seeds(Xd, 10, init_seeds=good)                              # num_init_seeds missing
+    with pytest.raises(ValueError):
+        MS.select_smart_seeds(Xd, 10, init_seeds=good[:5], num_init_seeds=2)        # wrong shape
+    with pytest.raises(ValueError):
+        MS.select_smart_seeds(Xd, 10, init_seeds=good, num_init_seeds=11)
+    with pytest.raises(ValueError):
+        MS.select_smart_seeds(Xd, 10, init_seeds=good.cpu(), num_init_seeds=2)      # other device
 
 
 def test_public_api_types_and_rng(device):

@@ -44,6 +44,8 @@ def test_argument_validation_without_gpu():
     assert b"null" in lib.uoc_last_error().lower()
     rc = lib.uoc_ms_seed_components(None, 1, 1000, 0.04, None, None, None)
     assert rc == -22
+    rc = lib.uoc_ms_select_seeds_from(None, 1, 100, 10, 3, None, None, None, None, 0, None)      # continuation entry
+    assert rc == -22
     # 128-d entry points: halves in {1, 2}; the 2-plane workspace is larger
     assert lib.uoc_ms_workspace_bytes_wide(1, 50176, 100, 2) > lib.uoc_ms_workspace_bytes_wide(1, 50176, 100, 1) > 0
     assert lib.uoc_ms_workspace_bytes_wide(1, 50176, 100, 1) == lib.uoc_ms_workspace_bytes(1, 50176, 100)

@@ -30,6 +30,7 @@ def _declare(lib):
     lib.uoc_ms_workspace_bytes.restype = c_size_t
     lib.uoc_ms_workspace_bytes.argtypes = [c_int, c_int, c_int]
     lib.uoc_ms_select_seeds.argtypes = [P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]
+    lib.uoc_ms_select_seeds_from.argtypes = [P, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, P]
     lib.uoc_ms_hill_climb.argtypes = [P, c_int, c_int, P, c_int, c_float, c_int, P, c_size_t, P]
     lib.uoc_ms_seed_components.argtypes = [P, c_int, c_int, c_float, P, P, P]
     lib.uoc_ms_assign.argtypes = [P, c_int, c_int, P, P, P, c_int, P, P, P, c_size_t, P]
@@ -76,14 +77,14 @@ def _declare(lib):
     lib.uoc_prof_report.argtypes = [ctypes.c_char_p, c_size_t]
     for name in ("uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report"):
         getattr(lib, name).restype = c_int
-    for name in ("uoc_ms_select_seeds", "uoc_ms_hill_climb", "uoc_ms_seed_components", "uoc_ms_assign",
+    for name in ("uoc_ms_select_seeds", "uoc_ms_select_seeds_from", "uoc_ms_hill_climb", "uoc_ms_seed_components", "uoc_ms_assign",
                  "uoc_ms_cluster"):
         getattr(lib, name).restype = c_int
 
 
 # every symbol include/uoc_hip.h declares (tests check the .so exports them all)
 EXPORTED_SYMBOLS = (
-    "uoc_version", "uoc_shutdown", "uoc_last_error", "uoc_ms_set_persistent_fps", "uoc_ms_set_stream_ordering", "uoc_ms_fps_fallbacks", "uoc_ms_check", "uoc_ms_workspace_bytes", "uoc_ms_select_seeds", "uoc_ms_hill_climb",
+    "uoc_version", "uoc_shutdown", "uoc_last_error", "uoc_ms_set_persistent_fps", "uoc_ms_set_stream_ordering", "uoc_ms_fps_fallbacks", "uoc_ms_check", "uoc_ms_workspace_bytes", "uoc_ms_select_seeds", "uoc_ms_select_seeds_from", "uoc_ms_hill_climb",
     "uoc_ms_seed_components", "uoc_ms_assign", "uoc_ms_cluster", "uoc_ms_workspace_bytes_wide", "uoc_ms_cluster_wide",
     "uoc_net_embed_dim",
     "uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",

@@ -63,7 +63,7 @@ __device__ __forceinline__ ArgMax wave_argmax(ArgMax v) {
 // is the sum over the halves.
 template <int NH>
 __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
-    const float *__restrict__ X, int n, int m, int step, const int *__restrict__ first_index,
+    const float *__restrict__ X, int n, int m, int step, int num_init, const int *__restrict__ first_index,
     float *__restrict__ dmin, float *__restrict__ seeds, int *__restrict__ indices,
     const ArgMax *__restrict__ part_in, ArgMax *__restrict__ part_out) {
   const int b = blockIdx.y;
@@ -78,8 +78,13 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
   __shared__ ArgMax red[FPS_THREADS / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+  // continuation (select_smart_seeds(init_seeds=..., num_init_seeds=k), :142-170): rows 0..k-1 of `seeds` are the
+  // caller's; their steps only fold their distances into dmin and record index -1
+  const bool given = step < num_init;
   int cur;
-  if (step == 0) {
+  if (given) {
+    cur = -1;
+  } else if (step == 0) {
     cur = first_index[b];
     if (cur < 0 || cur >= n) cur = 0;  // the host mirrors validate; never read outside X
   } else {
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
   }
   if (blockIdx.x == 0) {
     if (tid == 0) indices[step] = cur;
-    if (tid < NH * C)
+    if (!given && tid < NH * C)
       seeds[((size_t)(tid / C) * m + step) * C + tid % C] = X[((size_t)(tid / C) * n + cur) * C + tid % C];
   }
   if (step == m - 1) return;  // the distances to the last seed are never consumed (:174 uses [:, :i])
@@ -109,7 +114,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_step_kernel(
   const int t = lane & 15, g = lane >> 4;
   float4 sv[NH];
 #pragma unroll
-  for (int h = 0; h < NH; ++h) sv[h] = *reinterpret_cast<const float4 *>(X + ((size_t)h * n + cur) * C + 4 * t);
+  for (int h = 0; h < NH; ++h)
+    sv[h] = given ? *reinterpret_cast<const float4 *>(seeds + ((size_t)h * m + step) * C + 4 * t)
+                  : *reinterpret_cast<const float4 *>(X + ((size_t)h * n + cur) * C + 4 * t);
   ArgMax best = {-INFINITY, INT_MAX};
   const int nchunk = (n + 63) >> 6;
   for (int chunk = blockIdx.x * (FPS_THREADS / 64) + wave; chunk < nchunk; chunk += nblk * (FPS_THREADS / 64)) {
@@ -1213,7 +1220,7 @@ static int fps_persistent_plan(int batch, int n, int *bpi, int *nslots) {
 }
 
 static int run_select_seeds_streaming(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
-                                      int32_t *indices, const MsWorkspace &w, hipStream_t st);
+                                      int32_t *indices, const MsWorkspace &w, hipStream_t st, int num_init = 0);
 
 // One event per device that orders the persistent sampling kernels of all streams (see run_select_seeds).
 struct FpsChain {
@@ -1310,7 +1317,7 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
 }
 
 static int run_select_seeds_streaming(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
-                                      int32_t *indices, const MsWorkspace &w, hipStream_t st) {
+                                      int32_t *indices, const MsWorkspace &w, hipStream_t st, int num_init) {
   const int nblk = fps_blocks(n);
   for (int s = 0; s < m; ++s) {
     dim3 grid(nblk, batch);  // gridDim.x doubles as the partial count, so it is the same every step
@@ -1318,11 +1325,11 @@ static int run_select_seeds_streaming(const float *X, int batch, int n, int m, c
     ProfScope prof(KC_FPS_STEP, st, last ? 0.0 : 2.0 * batch * n * C * w.nh,
                    last ? 0.0 : 4.0 * batch * ((double)n * C * w.nh + 2.0 * n));
     if (w.nh == 2)
-      hipLaunchKernelGGL(fps_step_kernel<2>, grid, dim3(FPS_THREADS), 0, st, X, n, m, s, first, w.dmin, seeds, indices,
-                         w.part[(s + 1) & 1], w.part[s & 1]);
+      hipLaunchKernelGGL(fps_step_kernel<2>, grid, dim3(FPS_THREADS), 0, st, X, n, m, s, num_init, first, w.dmin, seeds,
+                         indices, w.part[(s + 1) & 1], w.part[s & 1]);
     else
-      hipLaunchKernelGGL(fps_step_kernel<1>, grid, dim3(FPS_THREADS), 0, st, X, n, m, s, first, w.dmin, seeds, indices,
-                         w.part[(s + 1) & 1], w.part[s & 1]);
+      hipLaunchKernelGGL(fps_step_kernel<1>, grid, dim3(FPS_THREADS), 0, st, X, n, m, s, num_init, first, w.dmin, seeds,
+                         indices, w.part[(s + 1) & 1], w.part[s & 1]);
   }
   UOC_LAUNCH_CHECK();
   return UOC_OK;
@@ -1535,6 +1542,18 @@ int uoc_ms_select_seeds(const float *d_X, int batch, int n, int m, const int32_t
   UOC_REQUIRE(d_first_index && d_seeds && d_indices, "null output/first_index pointer");
   return run_select_seeds(d_X, batch, n, m, d_first_index, d_seeds, d_indices, carve(d_ws, batch, n),
                           (hipStream_t)stream);
+}
+
+int uoc_ms_select_seeds_from(const float *d_X, int batch, int n, int m, int num_init, const int32_t *d_first_index,
+                             float *d_seeds, int32_t *d_indices, void *d_ws, size_t ws_bytes, void *stream) {
+  if (int rc = check_common(d_X, batch, n, m, d_ws, ws_bytes)) return rc;
+  UOC_REQUIRE(d_seeds && d_indices && ((uintptr_t)d_seeds & 15) == 0, "seeds / indices null or seeds not 16-byte aligned");
+  UOC_REQUIRE(num_init >= 0 && num_init <= m, "num_init=%d out of range [0, %d]", num_init, m);
+  UOC_REQUIRE(num_init > 0 || d_first_index, "null first_index pointer");
+  if (num_init == 0)
+    return run_select_seeds(d_X, batch, n, m, d_first_index, d_seeds, d_indices, carve(d_ws, batch, n), (hipStream_t)stream);
+  return run_select_seeds_streaming(d_X, batch, n, m, d_first_index, d_seeds, d_indices, carve(d_ws, batch, n),
+                                    (hipStream_t)stream, num_init);
 }
 
 int uoc_ms_hill_climb(const float *d_X, int batch, int n, float *d_Z, int m, float kappa, int iters, void *d_ws,

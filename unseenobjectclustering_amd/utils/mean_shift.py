@@ -140,22 +140,38 @@ def mean_shift_smart_init(X, kappa, num_seeds=100, max_iters=10, metric="cosine"
 
 def select_smart_seeds(X, num_seeds, return_selected_indices=False, init_seeds=None, num_init_seeds=None,
                        metric="cosine"):
-    """mean_shift.py:128-189 (init_seeds continuation is not used on the hot path and not implemented)."""
+    """mean_shift.py:128-189.  With init_seeds [num_seeds, d] (first num_init_seeds rows already chosen, :142-170) the
+    selection continues from them and — as in the reference, where `seeds = init_seeds` — is written into that tensor;
+    the returned indices are -1 for the given rows.  The global RNG is drawn only when no seed is given yet (:154-155)."""
     _require_cosine(metric)
-    if init_seeds is not None:
-        raise NotImplementedError("init_seeds continuation is not part of the inference hot path")
     X = _check_points(X)
     n = X.shape[0]
     dev = X.device
     L = _native.lib()
-    first = torch.tensor([np.random.randint(0, n)], dtype=torch.int32).to(dev)
-    seeds = torch.empty((num_seeds, EMBED_DIM), dtype=torch.float32, device=dev)
+    if init_seeds is None:
+        seeds = torch.empty((num_seeds, EMBED_DIM), dtype=torch.float32, device=dev)
+        num_init = 0
+    else:
+        if num_init_seeds is None:
+            raise TypeError("num_init_seeds is required with init_seeds")      # the reference fails on range(None) / None == 0
+        num_init = int(num_init_seeds)
+        if tuple(init_seeds.shape) != (num_seeds, EMBED_DIM) or init_seeds.device != dev:
+            raise ValueError(f"init_seeds must be [{num_seeds}, {EMBED_DIM}] on {dev}; got {tuple(init_seeds.shape)} on "
+                             f"{init_seeds.device}")
+        if not 0 <= num_init <= num_seeds:
+            raise ValueError(f"num_init_seeds={num_init} out of range [0, {num_seeds}]")
+        if init_seeds.dtype != torch.float32 or not init_seeds.is_contiguous():
+            raise TypeError("init_seeds must be a contiguous float32 tensor (it receives the selection in place)")
+        seeds = init_seeds
+    first = None
+    if num_init == 0:
+        first = torch.tensor([np.random.randint(0, n)], dtype=torch.int32).to(dev)
     indices = torch.empty((num_seeds,), dtype=torch.int32, device=dev)
     ws = _workspace(dev, L.uoc_ms_workspace_bytes(1, n, num_seeds))
     with torch.cuda.device(dev):
-        rc = L.uoc_ms_select_seeds(_native.ptr(X), 1, n, num_seeds, _native.ptr(first), _native.ptr(seeds),
-                                   _native.ptr(indices), _native.ptr(ws), ws.numel(), _native.stream_ptr(dev))
-    _native.check(rc, "uoc_ms_select_seeds")
+        rc = L.uoc_ms_select_seeds_from(_native.ptr(X), 1, n, num_seeds, num_init, _native.ptr(first), _native.ptr(seeds),
+                                        _native.ptr(indices), _native.ptr(ws), ws.numel(), _native.stream_ptr(dev))
+    _native.check(rc, "uoc_ms_select_seeds_from")
     if return_selected_indices:
         return seeds, indices.long().cpu()
     return (seeds,)
