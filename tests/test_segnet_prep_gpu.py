@@ -129,3 +129,35 @@ def test_tools_test_net_on_a_synthetic_osd_tree(device, tmp_path):
         # precision: measured F = 0.64 / 0.61; every annotated object is found
         assert r["metrics_refined"]["Objects F-measure"] > 0.5 and r["metrics_refined"]["Objects Recall"] > 0.8, r["metrics_refined"]
         assert r["metrics_refined"]["obj_detected"] >= r["metrics_refined"]["obj_gt"] >= 5
+
+
+def test_ros_node_publishes_the_reference_labels_for_the_demo_frame(golden_dir, device):
+    """ros/test_images_segmentation.py driven by a fake ROS bundle with the real two-stage path: the mono8 label topics
+    for the demo frame equal the label maps the reference's test_sample produced (tests/golden/demo.npz)."""
+    from tests import fake_ros
+    from tests.test_ros_node import load_node_module
+    from unseenobjectclustering_amd import networks, synth
+    cfg.device = device
+    g = np.load(os.path.join(golden_dir, "demo.npz"))
+    d = os.path.join(golden_dir, "demo")
+    cam = json.load(open(os.path.join(d, "camera_params.json")))
+    im, dep = uio.load_images(os.path.join(d, "000002-color.png"), os.path.join(d, "000002-depth.png"))
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    net = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    ros = fake_ros.make([cam["fx"], 0, cam["x_offset"], 0, cam["fy"], cam["y_offset"], 0, 0, 1])
+    saved = cfg.TEST.ROS_CAMERA, cfg.TEST.SCALES_BASE
+    cfg.TEST.ROS_CAMERA, cfg.TEST.SCALES_BASE = "camera", (1.0,)
+    try:
+        node = load_node_module().SegmentationNode(net, net, ros)
+        node.on_rgbd(fake_ros.Image(im, "bgr8", "camera_rgb_optical_frame", 7.0), fake_ros.Image(dep, "16UC1"))
+        np.random.seed(3)
+        assert node.spin_once()
+    finally:
+        cfg.TEST.ROS_CAMERA, cfg.TEST.SCALES_BASE = saved
+    from oracle.mean_shift_oracle import labels_equal_up_to_permutation
+    lab, = node.pub["seg_label"].sent
+    ref, = node.pub["seg_label_refined"].sent
+    assert lab.encoding == ref.encoding == "mono8" and lab.header.stamp == 7.0
+    assert labels_equal_up_to_permutation(lab.data, g["out_label"].astype(np.uint8))
+    assert labels_equal_up_to_permutation(ref.data, g["refined"].astype(np.uint8))
+    assert node.pub["seg_image"].sent[0].data.shape == (480, 640, 3)

@@ -28,12 +28,18 @@ def load_images(filename_color, filename_depth):
 
 def make_sample(im_bgr_u8, depth_u16, camera_params):
     """tools/test_images.py:112-133 on decoded arrays."""
+    depth = depth_u16.astype(np.float32) / 1000.0 if cfg.INPUT in ("DEPTH", "RGBD") else None
+    return make_sample_metric(im_bgr_u8, depth, camera_params["fx"], camera_params["fy"], camera_params["x_offset"],
+                              camera_params["y_offset"])
+
+
+def make_sample_metric(im_bgr_u8, depth_m, fx, fy, px, py):
+    """The same from a depth image already in metres (float32) — what the ROS node holds after decoding a 32FC1 /
+    16UC1 message (ros/test_images_segmentation.py:139-155 runs the same arithmetic as tools/test_images.py:112-133)."""
     sample = {}
     if cfg.INPUT in ("DEPTH", "RGBD"):
-        depth = depth_u16.astype(np.float32) / 1000.0
-        height, width = depth.shape
-        xyz_img = compute_xyz(depth, camera_params["fx"], camera_params["fy"], camera_params["x_offset"],
-                              camera_params["y_offset"], height, width)
+        height, width = depth_m.shape
+        xyz_img = compute_xyz(depth_m, fx, fy, px, py, height, width)
         sample["depth"] = torch.from_numpy(xyz_img).permute(2, 0, 1).unsqueeze(0)
     im_tensor = torch.from_numpy(im_bgr_u8) / 255.0
     im_tensor -= torch.tensor(cfg.PIXEL_MEANS / 255.0).float()
