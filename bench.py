@@ -245,7 +245,7 @@ def main():
                     help="strong scaling: this many frames in total, sharded in contiguous blocks over the GPUs")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cpu-frames", type=int, default=3, help="frames for the CPU baseline + parity (0 = skip)")
-    ap.add_argument("--profile-steps", type=int, default=4)
+    ap.add_argument("--profile-steps", type=int, default=4, help="launch sets in the profiled pass (0 = skip)")
     ap.add_argument("--sustained-seconds", type=float, default=10.0, help="sustained leg at N=1 (0 = skip)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("UOC_FRAMES_IN_FLIGHT", "3")),
                     help="streams per GPU, each working on one launch set of --frames-per-launch frames (runner._run_block_pipelined)")
@@ -388,12 +388,17 @@ def main():
     # ---- profiled pass (HIP events around every launch; separate from the timed region) ----
     roof, kernels = None, []
     if solo and args.profile_steps > 0:
+        # the launch shapes of the timed region (launch sets of --frames-per-launch frames), but one launch set at a time
+        # on one stream: the HIP events around a launch then time that kernel alone
+        nprof = min(hi - lo, args.profile_steps * max(1, args.frames_per_launch))
         _native.prof_enable(True)
-        for g in range(lo, min(hi, lo + args.profile_steps)):
-            np.random.seed(runner.frame_rng_seed(g))
-            frame_fn(g)
+        if args.frames_per_launch > 1:
+            runner.run_sharded(nprof, frame_fn, h, w, device, 0, 1, False, inflight=1)
+        else:
+            for g in range(lo, lo + nprof):
+                np.random.seed(runner.frame_rng_seed(g))
+                frame_fn(g)
         sync()
-        nprof = min(hi, lo + args.profile_steps) - lo
         rep = _native.prof_report()
         _native.prof_enable(False)
         tot = sum(r["total_ms"] for r in rep) or 1.0
@@ -413,7 +418,8 @@ def main():
             ach = dom["flops"] / sec / 1e12
             roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                    "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2)}
+                    "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
+                    "frames_per_launch": max(1, args.frames_per_launch)}
             if dom["kernel"] == "wino_gemm":
                 # the prof class counts the ALGORITHMIC (direct 3x3) flops; Winograd F(2x2,3x3) issues 16/36 of them
                 # to the matrix pipe.  `achieved` / `frac` are the flops the pipe really executes (a fraction of a

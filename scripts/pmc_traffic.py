@@ -1,20 +1,26 @@
 """Turn the FETCH_SIZE / WRITE_SIZE passes of scripts/profile_round.sh into profiles/<round>_pmc_traffic.md and
 profiles/traffic.json (HBM-side bytes per launch per bench kernel class, read by bench.py).
 
-    python scripts/pmc_traffic.py gpurun_out/prof_v7 profiles/r01_pmc_traffic.md
+    python scripts/pmc_traffic.py gpurun_out/prof_v7 profiles/r01_pmc_traffic.md [tail_fraction]
+
+tail_fraction (default 1): keep only the last fraction of the dispatches (by dispatch id) — the launch sets of the warm-up
+and timed region, without the single-frame first-use runs of the set-up.
 
 FETCH_SIZE is doubled for gfx950 (MI355X_MICROARCH.md, HBM section: 128-B requests are tallied as 64 B);
 WRITE_SIZE is used as reported; both counters are in KB and include Infinity-Cache hits."""
 import collections, csv, glob, json, os, re, sys
 
 
-def load(d, counter):
+def load(d, counter, frac=1.0):
     acc = collections.defaultdict(float)
     calls = collections.Counter()
     seen = set()
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] != counter:
+        rows = list(csv.DictReader(open(f)))
+        ids = [int(r["Dispatch_Id"]) for r in rows]
+        first = max(ids) - (max(ids) - min(ids)) * frac if ids else 0
+        for r in rows:
+            if r["Counter_Name"] != counter or int(r["Dispatch_Id"]) < first:
                 continue
             name = re.sub(r"\(.*$", "", re.sub(r"^void ", "", r["Kernel_Name"]))
             acc[name] += float(r["Counter_Value"])
@@ -38,9 +44,9 @@ def klass(name):
     return None
 
 
-def main(src, out_md):
-    fetch, calls = load(os.path.join(src, "fetch"), "FETCH_SIZE")
-    write, _ = load(os.path.join(src, "write"), "WRITE_SIZE")
+def main(src, out_md, frac=1.0):
+    fetch, calls = load(os.path.join(src, "fetch"), "FETCH_SIZE", frac)
+    write, _ = load(os.path.join(src, "write"), "WRITE_SIZE", frac)
     rows = []
     for name in fetch:
         c = calls[name]
@@ -49,9 +55,9 @@ def main(src, out_md):
         rows.append((name, c, rd, wr))
     rows.sort(key=lambda r: -(r[2] + r[3]) * r[1])
     lines = ["# HBM-side traffic per launch from PMC counters (%s)" % os.path.basename(src.rstrip("/")), "",
-             "Commands: `rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python bench.py --steps 4 "
-             "--warmup 1 --cpu-frames 0 --profile-steps 0` and the same with `--pmc WRITE_SIZE` (separate passes; "
-             "scripts/profile_round.sh).", "FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950 "
+             "Commands: `rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -- python bench.py --steps 6 "
+             "--warmup 3 --inflight 1 --cpu-frames 0 --profile-steps 0` (one launch set of 3 frames at a time) and the same "
+             "with `--pmc WRITE_SIZE` (separate passes; scripts/profile_round.sh); last %d %% of the dispatches." % round(100 * frac), "FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950 "
              "(128-B requests tallied at 64 B); WRITE_SIZE as reported (uncalibrated); counters are in KB. "
              "Infinity-Cache hits are counted, so this is an upper bound on DRAM bytes.", "",
              "| kernel | launches | read MB / launch | written MB / launch | total MB / launch |", "|---|---:|---:|---:|---:|"]
@@ -73,4 +79,4 @@ def main(src, out_md):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)

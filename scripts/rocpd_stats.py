@@ -1,8 +1,9 @@
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace into the per-kernel stats table that
 `rocprofv3 --kernel-trace --stats` reports: calls, total / average / min / max duration, share.
 
-    python scripts/rocpd_stats.py gpurun_out/prof_r01/bench_results.db > profiles/r01_kernel_stats.md
-"""
+    python scripts/rocpd_stats.py gpurun_out/prof_r01/bench_results.db [tail_fraction] > profiles/r01_kernel_stats.md
+tail_fraction (default 1 = whole trace): keep only the dispatches that start in the last fraction of the trace by time —
+the benchmark's timed region and profiled pass, without the set-up (tuner launches, single-frame first-use runs)."""
 import re
 import sqlite3
 import sys
@@ -14,11 +15,15 @@ def short(name: str) -> str:
     return name[:110]
 
 
-def main(path):
+def main(path, frac=1.0):
     db = sqlite3.connect(path)
+    t0, t1 = db.execute("select min(start), max(end) from kernels").fetchone()
+    w0 = t1 - (t1 - t0) * frac
     rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
-                      "max(vgpr_count), max(accum_vgpr_count), max(lds_size) from kernels group by name "
-                      "order by sum(duration) desc").fetchall()
+                      "max(vgpr_count), max(accum_vgpr_count), max(lds_size) from kernels where start >= ? group by name "
+                      "order by sum(duration) desc", (w0,)).fetchall()
+    if frac < 1.0:
+        print(f"window: last {frac:.0%} of the trace by time ({(t1 - w0) / 1e6:.1f} ms)\n")
     total = sum(r[2] for r in rows) or 1
     print("| kernel | calls | total ms | avg us | min us | max us | % GPU time | vgpr | agpr | lds B |")
     print("|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|")
@@ -28,4 +33,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], float(sys.argv[2]) if len(sys.argv) > 2 else 1.0)
