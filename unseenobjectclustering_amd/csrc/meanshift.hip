@@ -816,6 +816,10 @@ __global__ __launch_bounds__(HCR_THREADS) void hc_iter_reg_kernel(const float *_
 // all ST seed tiles (~330 of its 512 registers), X read exactly once.  Cost model that fits the measurements: a pixel
 // tile costs 32 cycles per MFMA (224) + 2 per VALU (~230) + 8 per v_exp (28) + ~2.7 per MFMA->VALU switch, i.e. the
 // floor of this formulation is ~8 000 cycles per tile against 7 168 of pure MFMA.
+// The 112 KB of LDS serve the epilogue only.  A variant whose waves meet through ONE wave-sized buffer (28 KB, three
+// hand-overs, same summation order) was measured in the three-stream pipeline, on the idea that the block would then
+// share a CU with another stream's convolution block: 122.7-123.1 vs 122.5-123.9 frames/s sustained, the kernel itself
+// +1.5 % — no gain (its 344 registers per lane leave room only for the smallest convolution tiles anyway); not kept.
 template <int ST, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void hc_iter_reg1_kernel(
     const float *__restrict__ X, int n, const float *__restrict__ Z, int m, float kappa, float *__restrict__ partial) {
