@@ -38,3 +38,31 @@ def test_block_is_independent_of_frames_in_flight(device):
     assert _native.lib().uoc_ms_fps_fallbacks() == before
     # stage 2 really ran: ROI counts recorded per frame
     assert len(counts[1, 1]) == 5 and min(counts[1, 1]) >= 5
+
+
+def test_launch_sets_with_frames_that_have_no_roi(device):
+    """Frames whose objects are all rejected by the depth filter (no ROI, stage 2 skipped, test_dataset.py:251-254)
+    mixed into launch sets with ordinary frames, and a launch set made only of such frames: same label maps and ROI
+    counts as one frame at a time."""
+    cfg.device = device
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    net = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    net_crop = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    samples = []
+    for g, blind in enumerate((False, True, False, True, True, True, False)):
+        fr = synth.palette_frame(10_000 + g, 480, 640, 5 + g % 3)
+        depth = np.zeros_like(fr["depth"]) if blind else fr["depth"]      # z = 0 everywhere: every label fails the filter
+        samples.append(dict(image_color=torch.from_numpy(fr["image_color"]).to(device), depth=torch.from_numpy(depth).to(device)))
+    blocks, counts = {}, {}
+    for depth, group in ((1, 1), (2, 3), (1, 4), (3, 2)):
+        fn = runner.two_stage_frame_fn(samples, net, net_crop, frames_per_launch=group)
+        blocks[depth, group] = runner.run_sharded(len(samples), fn, 480, 640, device, 0, 1, False, inflight=depth).cpu()
+        torch.cuda.synchronize()
+        counts[depth, group] = list(fn.roi_counts)
+    ref = blocks[1, 1]
+    assert counts[1, 1][1] == counts[1, 1][3] == counts[1, 1][4] == counts[1, 1][5] == 0 and min(counts[1, 1][0::2][:2]) >= 5
+    for blind in (1, 3, 4, 5):
+        assert int(ref[blind].max()) == 0          # everything filtered: the stage-1 map that is returned is background
+    for key, b in blocks.items():
+        assert torch.equal(ref, b), f"streams={key[0]} frames_per_launch={key[1]} changed a label map"
+        assert counts[key] == counts[1, 1]
