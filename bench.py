@@ -91,6 +91,10 @@ def cpu_model_name():
     return None
 
 
+# UOC_BENCH_CPU_SECONDS: a longer CPU sample for parity statistics over more frames (default: the bounded ~30 s sample)
+CPU_SAMPLE_SECONDS = float(os.environ.get("UOC_BENCH_CPU_SECONDS", "30"))
+
+
 def cpu_baseline(frames, out_path):
     """The oracle's two-stage test_sample on the host cores (torch CPU ops = the reference's ops), on global frames
     0..frames-1 of the benchmark set with the runner's per-frame RNG seeds.  Label maps go to `out_path` (npz)."""
@@ -114,7 +118,7 @@ def cpu_baseline(frames, out_path):
                                       np.random.RandomState(runner.frame_rng_seed(g)))
         maps.append((refined if refined is not None else out)[0].numpy().astype(np.int32))
         stage1.append(out[0].numpy().astype(np.int32))
-        if time.time() - t0 > 30.0:          # bounded sample: stop after ~30 s of CPU work
+        if time.time() - t0 > CPU_SAMPLE_SECONDS:          # bounded sample: stop after ~30 s of CPU work
             break
     dt = time.time() - t0
     done = len(maps)
@@ -128,6 +132,7 @@ def cpu_baseline(frames, out_path):
 
 def cpu_baseline_subprocess(frames, out_path, limit_s=300):
     """Runs the CPU leg in a child process so a slow host can never stall the GPU benchmark."""
+    limit_s = max(limit_s, 2.0 * CPU_SAMPLE_SECONDS + 120.0)
     fail = {"value": None, "unit": "frames/s", "cores": None, "cpu_model": cpu_model_name(), "kind": "port"}
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", str(frames),
