@@ -64,6 +64,12 @@ def _palette(g):
     return fr["image_color"], fr["depth"]
 
 
+def _block(total, rank, world):
+    """This rank's contiguous frame block — runner.shard_range without importing the package (bench.main asserts equality)."""
+    per = (total + world - 1) // world
+    return min(rank * per, total), min((rank + 1) * per, total)
+
+
 def host_frames(lo, hi):
     """Synthetic inputs of the global frames [lo, hi) as numpy arrays (a process pool for big blocks)."""
     idx = list(range(lo, hi))
@@ -280,6 +286,11 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     stub = args.stub
+    strong = args.frames > 0
+    total = args.frames if strong else args.steps * world
+    # host-side inputs first: big blocks are generated by forked workers, and forking is only clean before this process
+    # has a HIP context or RCCL threads
+    host = None if stub else host_frames(*_block(total, rank, world))
     if stub:
         device, backend, h, w = torch.device("cpu"), "gloo", 12, 16
     else:
@@ -297,9 +308,8 @@ def main():
     from unseenobjectclustering_amd import runner
     sync = (lambda: None) if stub else torch.cuda.synchronize
 
-    strong = args.frames > 0
-    total = args.frames if strong else args.steps * world
     lo, hi = runner.shard_range(total, rank, world)
+    assert (lo, hi) == _block(total, rank, world)
     K = (total + world - 1) // world            # frames per GPU = steps
     if stub:
         frame_fn = stub_frame_fn(h, w)
@@ -311,7 +321,6 @@ def main():
         sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
         network = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
         network_crop = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
-        host = host_frames(lo, hi)
         samples = [dict(image_color=torch.from_numpy(a).to(device), depth=torch.from_numpy(b).to(device)) for a, b in host]
         frame_fn = runner.two_stage_frame_fn(samples, network, network_crop, first_index=lo,     # global index -> resident sample
                                              frames_per_launch=args.frames_per_launch)
