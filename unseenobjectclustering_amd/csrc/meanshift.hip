@@ -1256,9 +1256,14 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
   // (stage 2 with > 8 ROIs) is split into several launches rather than dropped to the streaming kernel.
   int done = 0;
   while (m >= 2 && done < batch && w.nh == 1) {  // the on-chip kernel holds 64-d rows; 128-d fields stream
+    // the largest number of fields that stays on chip, then the remaining fields spread evenly over the launches
+    // that needs (21 crop fields: 7 + 7 + 7 instead of halving down to 6 + 6 + 6 + 3)
     int sub = batch - done, bpi = 0, nslots = 0;
-    while (sub > 1 && !fps_persistent_plan(sub, n, &bpi, &nslots)) sub = (sub + 1) / 2;
+    while (sub > 1 && !fps_persistent_plan(sub, n, &bpi, &nslots)) --sub;
     if (!fps_persistent_plan(sub, n, &bpi, &nslots)) break;
+    const int launches = (batch - done + sub - 1) / sub;
+    sub = (batch - done + launches - 1) / launches;
+    if (!fps_persistent_plan(sub, n, &bpi, &nslots)) break;  // (a smaller batch always fits if a larger one does)
     unsigned long long *gran = reinterpret_cast<unsigned long long *>(w.part[0]);
     int *status = reinterpret_cast<int *>(w.part[1]);
     const size_t gbytes = (size_t)2 * sub * bpi * sizeof(unsigned long long);
