@@ -199,6 +199,17 @@ def munkres_cases():
 PREP_SYNTH = dict(seed=5, H=37, W=53, camera=dict(fx=500.5, fy=499.25, x_offset=26.1, y_offset=18.7))
 
 
+def npy_frames():
+    """The two .npy layouts tools/test_npy.py reads (reference :107-123): a {'rgb', 'depth' mm} frame that needs
+    camera_params.json, and a {'debug_info': ...} frame that carries float32 intrinsics and a depth image in metres."""
+    im_bgr, dep = prep_synthetic_arrays()
+    rgb = np.ascontiguousarray(im_bgr[:, :, ::-1])
+    plain = {"rgb": rgb, "depth": dep}
+    K = np.array([[500.5, 0, 26.1], [0, 499.25, 18.7], [0, 0, 1]], dtype=np.float32)
+    debug = {"debug_info": {"rgb": rgb[::-1].copy(), "depth_image": (dep[::-1].astype(np.float32) / 1000.0), "intrinsics": K}}
+    return {"plain": plain, "debug": debug}
+
+
 def prep_synthetic_arrays():
     """(BGR uint8 [H,W,3], depth uint16 [H,W] millimetres): full value ranges, a few zero-depth holes."""
     c = PREP_SYNTH

@@ -4,7 +4,7 @@ Imports the reference's own Python (through tests/golden/ref_harness.py) and rec
 outputs on repo-owned synthetic inputs.  The .npz files written next to this script are the
 fixtures tests/ compares the oracle (CPU) and the HIP path (GPU) against.
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [meanshift|seedcont|glue|backbone|e2e|demo|modes|evaluation|prep|segnet|all]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [meanshift|seedcont|glue|backbone|e2e|demo|modes|evaluation|prep|npy|segnet|all]
 """
 from __future__ import annotations
 
@@ -22,7 +22,7 @@ sys.path.insert(0, HERE)
 import ref_harness  # noqa: E402
 from cases import (SEED_CONTINUATION_CASES, continuation_inputs, MEANSHIFT_CASES, KAPPA, EPSILON, RNG_SEED, BACKBONE_CASES, GLUE_CASES, E2E_CASES,  # noqa: E402
                    MODES, MODE_BACKBONE_CASES, MODE_GLUE_CASES, MODE_E2E_CASES, WIDE_MEANSHIFT_CASES,
-                   EVAL_CASES, eval_pair, munkres_cases, PREP_SYNTH, prep_synthetic_arrays, SEGNET_RUNS, SegnetLoader,
+                   EVAL_CASES, eval_pair, munkres_cases, PREP_SYNTH, prep_synthetic_arrays, SEGNET_RUNS, SegnetLoader, npy_frames,
                    segnet_samples, segnet_stub_networks, SEGNET_METRIC_KEYS,
                    sample_positions, glue_inputs, crop_cluster_labels, e2e_stub_features)
 from unseenobjectclustering_amd import synth  # noqa: E402
@@ -359,6 +359,30 @@ def make_prep(ref):
     np.savez_compressed(os.path.join(HERE, "prep.npz"), **out)
 
 
+def make_npy(ref):
+    """The reference's OWN tools/test_npy.py read_sample (:105-144) on the two .npy layouts (tests/golden/cases.py
+    npy_frames), written to a temporary directory."""
+    import importlib
+    import tempfile
+    _install_cv2_reader()
+    tools = os.path.join(ref_harness.REFERENCE_ROOT, "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    tn = importlib.import_module("test_npy")
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, d in npy_frames().items():
+            f = os.path.join(td, name + ".npy")
+            np.save(f, d, allow_pickle=True)
+            s = tn.read_sample(f, PREP_SYNTH["camera"])
+            for key in ("image_color", "depth"):
+                a = s[key].numpy()
+                assert a.dtype == np.float32, (name, key, a.dtype)
+                out[f"{name}/{key}"] = a
+            print(name, {k: tuple(v.shape) for k, v in s.items()}, flush=True)
+    np.savez_compressed(os.path.join(HERE, "npy.npz"), **out)
+
+
 def make_segnet(ref):
     """a14: the reference's OWN test_segnet (lib/fcn/test_dataset.py:271-381) on three samples per dataset name, stub
     networks, cfg.TEST.VISUALIZE False (so it writes the .mat files), boundary_overlap stubbed to (0, 0) like
@@ -423,6 +447,8 @@ def main():
         make_meanshift(ref)
     if what in ("seedcont", "all"):
         make_seedcont(ref)
+    if what in ("npy", "all"):
+        make_npy(ref)
     if what in ("backbone", "all"):
         make_backbone(ref)
     if what in ("glue", "all"):

@@ -13,6 +13,7 @@ from oracle import glue_oracle as G
 from tests.golden.cases import (PREP_SYNTH, RNG_SEED, SEGNET_RUNS, SegnetLoader, prep_synthetic_arrays, segnet_samples,
                                 segnet_stub_networks)
 from unseenobjectclustering_amd import io as uio
+from unseenobjectclustering_amd.fcn.config import cfg
 
 
 @pytest.fixture(scope="module")
@@ -52,3 +53,34 @@ def test_oracle_test_segnet_matches_reference_golden(golden_dir, tag):
     for i, (pred, refined) in enumerate(got):
         assert np.array_equal(pred.astype(np.uint8), g[f"{tag}/{i}/labels"])
         assert np.array_equal(refined.astype(np.uint8), g[f"{tag}/{i}/labels_refined"])
+
+
+def test_npy_driver_read_sample_matches_the_reference(golden_dir, tmp_path):
+    """tools/test_npy.py read_sample (both .npy layouts) against the reference's own tools/test_npy.py:105-144
+    (tests/golden/npy.npz): bit-identical float32 tensors."""
+    import importlib.util
+    from tests.golden.cases import npy_frames
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("uoc_tools_test_npy", os.path.join(root, "tools", "test_npy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(golden_dir, "npy.npz"))
+    saved = cfg.INPUT
+    cfg.INPUT = "RGBD"
+    try:
+        for name, d in npy_frames().items():
+            f = str(tmp_path / (name + ".npy"))
+            np.save(f, d, allow_pickle=True)
+            s = mod.read_sample(f, PREP_SYNTH["camera"])
+            for key in ("image_color", "depth"):
+                assert s[key].dtype == torch.float32
+                assert np.array_equal(s[key].numpy(), g[f"{name}/{key}"]), (name, key)
+        # float64 intrinsics (what np.array(msg.K) or a json round trip gives) must not promote the result
+        d = npy_frames()["debug"]
+        d["debug_info"]["intrinsics"] = d["debug_info"]["intrinsics"].astype(np.float64)
+        f = str(tmp_path / "debug64.npy")
+        np.save(f, d, allow_pickle=True)
+        s = mod.read_sample(f, None)
+        assert s["depth"].dtype == torch.float32 and np.array_equal(s["depth"].numpy(), g["debug/depth"])
+    finally:
+        cfg.INPUT = saved

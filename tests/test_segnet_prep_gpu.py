@@ -161,3 +161,41 @@ def test_ros_node_publishes_the_reference_labels_for_the_demo_frame(golden_dir, 
     assert labels_equal_up_to_permutation(lab.data, g["out_label"].astype(np.uint8))
     assert labels_equal_up_to_permutation(ref.data, g["refined"].astype(np.uint8))
     assert node.pub["seg_image"].sent[0].data.shape == (480, 640, 3)
+
+
+def test_tools_test_npy_on_the_demo_frame(golden_dir, device, tmp_path):
+    """tools/test_npy.py end to end: the demo frame packed in both .npy layouts -> the reference's label maps."""
+    import importlib.util
+    from PIL import Image
+    from oracle.mean_shift_oracle import labels_equal_up_to_permutation
+    from unseenobjectclustering_amd import networks, synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("uoc_tools_test_npy", os.path.join(root, "tools", "test_npy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(golden_dir, "demo.npz"))
+    d = os.path.join(golden_dir, "demo")
+    cam = json.load(open(os.path.join(d, "camera_params.json")))
+    im, dep = uio.load_images(os.path.join(d, "000002-color.png"), os.path.join(d, "000002-depth.png"))
+    rgb = np.ascontiguousarray(im[:, :, ::-1])
+    src = tmp_path / "frames"
+    src.mkdir()
+    np.save(str(src / "a_plain.npy"), {"rgb": rgb, "depth": dep}, allow_pickle=True)
+    K = np.array([[cam["fx"], 0, cam["x_offset"]], [0, cam["fy"], cam["y_offset"]], [0, 0, 1]])
+    np.save(str(src / "b_debug.npy"), {"debug_info": {"rgb": rgb, "depth_image": dep.astype(np.float32) / 1000.0,
+                                                       "intrinsics": K}}, allow_pickle=True)
+    json.dump(cam, open(str(src / "camera_params.json"), "w"))
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    net = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    out = tmp_path / "labels"
+    # every frame draws its first seeds from the global RNG in turn; re-seed per frame through a one-frame directory
+    for name in ("a_plain", "b_debug"):
+        one = tmp_path / ("only_" + name)
+        one.mkdir()
+        os.link(str(src / (name + ".npy")), str(one / (name + ".npy")))
+        json.dump(cam, open(str(one / "camera_params.json"), "w"))
+        res = mod.main(["--imgdir", str(one), "--outdir", str(out)], networks_override=(net, net))     # seeds RNG_SEED = 3
+        assert len(res) == 1
+        lab = np.asarray(Image.open(str(out / (name + "-label.png"))))
+        assert labels_equal_up_to_permutation(lab, g["refined"].astype(np.uint8)), name
+        assert labels_equal_up_to_permutation(res[0][1].numpy(), g["out_label"]), name
