@@ -40,7 +40,7 @@ struct uoc_net {
   int stem = -1, fc = -1;
   bool finalized = false;
   int device = -1;
-  int wino_min_cin = 256;  // 3x3 stride-1 layers with Cin >= this run as Winograd F(2x2,3x3); 0 = never
+  int wino_min_cin = 128;  // 3x3 stride-1 layers with Cin >= this run as Winograd F(2x2,3x3); 0 = never
   int mode = UOC_NET_RGBD_ADD;
   int G = 2;  // backbones evaluated side by side (2 for RGBD 'add' and 'cat')
 };
