@@ -260,7 +260,7 @@ def main():
     ap.add_argument("--sustained-seconds", type=float, default=10.0, help="sustained leg at N=1 (0 = skip)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("UOC_FRAMES_IN_FLIGHT", "3")),
                     help="streams per GPU, each working on one launch set of --frames-per-launch frames (runner._run_block_pipelined)")
-    ap.add_argument("--frames-per-launch", type=int, default=int(os.environ.get("UOC_FRAMES_PER_LAUNCH", "3")),
+    ap.add_argument("--frames-per-launch", type=int, default=int(os.environ.get("UOC_FRAMES_PER_LAUNCH", "4")),
                     help="frames batched into one set of launches per stage (fcn.test_dataset.FrameGroupJob)")
     ap.add_argument("--skip-pcie", action="store_true", help="skip the PCIe-inclusive leg (profiling runs)")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, help=argparse.SUPPRESS)

@@ -24,7 +24,7 @@ def test_block_is_independent_of_frames_in_flight(device):
     before = _native.lib().uoc_ms_fps_fallbacks()
     blocks, counts = {}, {}
     # (streams, frames per launch): sequential / two streams / three streams, one or two frames per launch set
-    for depth, group in ((1, 1), (2, 1), (3, 1), (2, 2), (2, 3), (1, 2)):
+    for depth, group in ((1, 1), (2, 1), (3, 1), (2, 2), (2, 3), (1, 2), (3, 4)):
         fn = runner.two_stage_frame_fn(samples, net, net_crop, frames_per_launch=group)
         blocks[depth, group] = runner.run_sharded(5, fn, 480, 640, device, 0, 1, False, inflight=depth).cpu()
         torch.cuda.synchronize()

@@ -183,7 +183,7 @@ def two_stage_frame_fn(samples, network, network_crop, first_index: int = 0, fra
     """frame_fn over pre-uploaded samples: final label map = refined map if stage 2 produced one,
     else the stage-1 map (what test_segnet stores as labels_refined, test_dataset.py:324-327).
     Global frame i reads samples[(i - first_index) % len(samples)] (a rank passes the start of its block).
-    frames_per_launch (default $UOC_FRAMES_PER_LAUNCH or 3): frames the pipelined runner batches into one launch set
+    frames_per_launch (default $UOC_FRAMES_PER_LAUNCH or 4): frames the pipelined runner batches into one launch set
     (fcn.test_dataset.FrameGroupJob)."""
     from .fcn.test_dataset import _run_frame, _check_clustering, DEPTH_FILTER, LAST_FRAME_STATS, FrameGroupJob
 
@@ -205,7 +205,7 @@ def two_stage_frame_fn(samples, network, network_crop, first_index: int = 0, fra
         return n
     fn.make_job = make_job
     fn.group_size = group_size
-    fn.frames_per_launch = frames_per_launch if frames_per_launch is not None else int(os.environ.get("UOC_FRAMES_PER_LAUNCH", "3"))
+    fn.frames_per_launch = frames_per_launch if frames_per_launch is not None else int(os.environ.get("UOC_FRAMES_PER_LAUNCH", "4"))
     fn.roi_counts = []          # stage-1 ROIs per processed frame (the bench derives the algorithmic work from it)
     # every frame checks the clustering status once after stage 1 (a sticky device flag, so a stage-2 failure
     # surfaces at the next frame); fn.finish() is the check after the last frame
