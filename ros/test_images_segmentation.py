@@ -152,9 +152,12 @@ class SegmentationNode:
             self._publish("seg_image_refined", overlay(rgb, refined), "rgb8", frame_id, stamp)
         return True
 
-    def spin(self):
+    def spin(self, idle_sleep=0.002):
+        """Segments frames until ROS shuts down; sleeps briefly while no frame has arrived (the reference spins hot)."""
+        import time
         while not self.ros.rospy.is_shutdown():
-            self.spin_once()
+            if not self.spin_once():
+                time.sleep(idle_sleep)
 
 
 def parse_args(argv=None):

@@ -81,8 +81,9 @@ def main(argv=None, networks_override=None):
         if not args.pretrained:
             print("no pretrained network specified")          # :196-198
             sys.exit()
-        load = lambda path: (lambda data: data["model"] if isinstance(data, dict) and "model" in data else data)(
-            torch.load(path, map_location="cpu"))
+        def load(path):
+            data = torch.load(path, map_location="cpu")
+            return data["model"] if isinstance(data, dict) and "model" in data else data       # tools/test_net.py:110-112
         factory = networks.__dict__[args.network_name]
         network = factory(2, cfg.TRAIN.NUM_UNITS, load(args.pretrained)).eval()
         network_crop = factory(2, cfg.TRAIN.NUM_UNITS, load(args.pretrained_crop)).eval() if args.pretrained_crop else None
