@@ -428,12 +428,21 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if collected
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get(dom["kernel"])
-        if dom["kernel"].startswith(("conv", "wino_gemm")) or dom["kernel"] in ("hc_iter", "assign"):   # MFMA-bound classes
+        if dom["kernel"].startswith(("conv", "wino_gemm", "wino4_gemm")) or dom["kernel"] in ("hc_iter", "assign"):   # MFMA-bound classes
             ach = dom["flops"] / sec / 1e12
             roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                     "frames_per_launch": max(1, args.frames_per_launch)}
+            if dom["kernel"] == "wino4_gemm":
+                # algorithmic = the direct 3x3 convolution's flops; Winograd F(4x4,3x3) issues 36/144 of
+                # them to the matrix pipe (tile padding not counted: it is wasted work, not achieved work)
+                roof["algorithmic_tflops"] = roof["achieved"]
+                roof["algorithmic_frac"] = roof["frac"]
+                roof["achieved"] = round(ach * 0.25, 2)
+                roof["frac"] = round(ach * 0.25 / PEAK_FP32_TFLOPS, 4)
+                roof["note"] = ("Winograd F(4x4,3x3): achieved = MFMA flops executed for real outputs (36/144 of the direct "
+                                "conv's); algorithmic_* = SURVEY 8(d) direct-conv flops over the same time")
             if dom["kernel"] == "wino_gemm":
                 # the prof class counts the ALGORITHMIC (direct 3x3) flops; Winograd F(2x2,3x3) issues 16/36 of them
                 # to the matrix pipe.  `achieved` / `frac` are the flops the pipe really executes (a fraction of a

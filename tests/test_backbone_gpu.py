@@ -137,11 +137,23 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", WINO_CASES)
-def test_winograd_conv_vs_torch_cpu(device, case):
-    """Winograd F(2x2,3x3) path (csrc/wino.hip) against torch CPU conv2d; fp32 Winograd differs from the
-    direct sum only by rounding (bar: 2e-4 of the output scale, measured ~1e-6)."""
+WINO4_EXTRA_CASES = [
+    (2, 4, 60, 80, 256, 256, 2, True, True),      # stage-1 layer3 launch set of four frames: several items per block
+    (2, 9, 28, 28, 512, 512, 4, True, True),      # stage-2 layer4, nine crops
+    (1, 5, 28, 28, 128, 128, 1, False, True),     # stage-2 layer2: 7x7 tiles per crop, 4 cin chunks per item
+    (1, 1, 61, 83, 128, 256, 2, False, False),    # odd size, Cin != Cout
+]
+
+
+@pytest.mark.parametrize("algo", ["f2", "f4", "f4-planes-as-groups"])
+@pytest.mark.parametrize("case", WINO_CASES + WINO4_EXTRA_CASES)
+def test_winograd_conv_vs_torch_cpu(device, case, algo):
+    """Winograd paths — F(4x4,3x3) (csrc/wino4.hip; persistent plane GEMM, or the planes as groups of the direct 1x1
+    kernel) and F(2x2,3x3) (csrc/wino.hip) — against torch CPU conv2d; fp32 Winograd differs from the direct sum only by
+    rounding (bar: 2e-4 of the output scale, measured ~1e-6)."""
     G, B, H, W, Cin, Cout, dil, use_res, relu = case
+    if algo == "f2" and case in WINO4_EXTRA_CASES[:2]:
+        pytest.skip("large cases are for the F(4x4) item loop")
     g = torch.Generator().manual_seed(abs(hash(case)) % (2 ** 31))
     x = torch.randn(G, B, Cin, H, W, generator=g)
     w = torch.randn(G, Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
@@ -158,12 +170,14 @@ def test_winograd_conv_vs_torch_cpu(device, case):
     rd = res.permute(0, 1, 3, 4, 2).contiguous().to(device) if res is not None else None
     out = torch.empty((G, B, H, W, Cout), device=device)
     L = _native.lib()
-    os.environ["UOC_CONV_WINOGRAD"] = "1"
+    os.environ["UOC_CONV_WINOGRAD"] = "1" if algo == "f2" else "4"
+    os.environ["UOC_WINO4_GEMM"] = "1" if algo == "f4-planes-as-groups" else "2"
     try:
         rc = L.uoc_conv2d_nhwc(_native.ptr(xd), _native.ptr(wd), _native.ptr(bd), _native.ptr(rd), _native.ptr(out),
                                G, B, H, W, Cin, Cout, 3, 1, dil, dil, int(relu), _native.stream_ptr(device))
     finally:
         os.environ.pop("UOC_CONV_WINOGRAD", None)
+        os.environ.pop("UOC_WINO4_GEMM", None)
     _native.check(rc, "uoc_conv2d_nhwc (winograd)")
     got = out.cpu().permute(0, 1, 4, 2, 3)
     err = (got - ref).abs().max().item()

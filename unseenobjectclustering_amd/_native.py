@@ -154,6 +154,6 @@ def prof_enable(on: bool):
 def prof_report():
     """Per-kernel-class totals recorded since prof_enable(True): list of dicts."""
     import json
-    buf = ctypes.create_string_buffer(1 << 16)
+    buf = ctypes.create_string_buffer(1 << 19)
     check(lib().uoc_prof_report(buf, len(buf)), "uoc_prof_report")
     return json.loads(buf.value.decode())

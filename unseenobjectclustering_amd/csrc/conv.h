@@ -10,13 +10,18 @@ namespace uoc {
 struct ConvParams {
   const float *in;    // [G][B][H][W][Cin]
   const float *w;     // [G][T][Cout][Kc]
-  const float *bias;  // [G][Cout]
+  const float *bias;  // [G][Cout]; nullptr = no bias (the Winograd F(4x4) plane GEMMs)
   const float *res;   // [G][B][Ho][Wo][Cout] or nullptr
   float *out;         // [G][B][Ho][Wo][Cout]
   int G, B, H, W, Cin, Ho, Wo, Cout;
   int KH, KW, stride, dil, pad, relu;
   int stem;           // 1: 7x7 s2 p3 conv over NHWC4 input, K-chunk = one kernel row
   int tune = 1;       // 0: never autotune for this call (generic C entry: the tuner re-launches into `out` and syncs)
+  // profiling overrides (csrc/prof.h): a caller that uses this convolution as a building block books it under its own
+  // kernel class, algorithmic flop count and shape tag
+  int prof_kc = -1;
+  double prof_flops = 0.0;
+  int prof_tag[4] = {0, 0, 0, 0};
 };
 
 int launch_conv(const ConvParams &p, hipStream_t st);
@@ -27,6 +32,13 @@ bool wino_eligible(const ConvParams &p);
 size_t wino_v_floats(int G, int B, int H, int W, int d, int Cin);
 int launch_wino_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st);
 int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_t st);
+
+// Winograd F(4x4,3x3) path (csrc/wino4.hip): U = transformed weights [G*36][Cout][Cin] (launch_wino4_weights, computed
+// in double), ws = scratch of wino4_ws_floats() floats (the V and M frequency planes).
+bool wino4_eligible(const ConvParams &p);
+size_t wino4_ws_floats(int G, int B, int H, int W, int d, int Cin, int Cout);
+int launch_wino4_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st);
+int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_t st);
 
 // NCHW [B][3][H][W] -> NHWC4 [B][H][W][4] (4th channel = 0)
 int launch_nchw3_to_nhwc4(const float *in, float *out, int B, int H, int W, hipStream_t st);

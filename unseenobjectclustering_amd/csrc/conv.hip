@@ -18,6 +18,7 @@
 #include "conv.h"
 
 #include <mutex>
+#include "dma.h"
 #include "prof.h"
 
 #include <stdlib.h>
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvPa
 
   const float *__restrict__ in = p.in + (size_t)g * p.B * p.H * p.W * p.Cin;
   const float *__restrict__ w = p.w + (size_t)g * T * p.Cout * Kc;
-  const float *__restrict__ bias = p.bias + (size_t)g * p.Cout;
+  const float *__restrict__ bias = p.bias ? p.bias + (size_t)g * p.Cout : nullptr;
   const float *__restrict__ res = p.res ? p.res + (size_t)g * M * p.Cout : nullptr;
   float *__restrict__ out = p.out + (size_t)g * M * p.Cout;
 
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvPa
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn * WN + 16 * j + 4 * q;
-    const float4 bv = *reinterpret_cast<const float4 *>(bias + co);
+    const float4 bv = bias ? *reinterpret_cast<const float4 *>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + wm * WM + 16 * i + t;
@@ -228,41 +229,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvPa
 // -------------------------------------------------------------------------------------------
 __device__ float4 g_zero_page[8];  // zero-initialised device memory
 
-// One LDS-DMA: 64 lanes x 16 B land at LDS byte address `lds_dst` (wave-uniform) + 16*lane.  Written
-// as inline asm so that hipcc does not count it: with the builtin, the compiler drains the DMA queue
-// (s_waitcnt vmcnt(0)) in front of every ds_read; here the counted waits below are the only ones.
-// M0 carries the LDS base.  It is written without save / restore (two scalar moves per DMA less; see wglds16s in
-// wino.hip): nothing else in these kernels lives in m0 and hipcc sets it itself right before any use of its own.
-__device__ __forceinline__ void glds16(const float *g, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_dst) : "memory");
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// The same through a raw buffer descriptor: address = descriptor base + soff (wave-uniform SGPR) + voff (per lane);
-// a lane whose voff lies beyond the descriptor's num_records delivers ZEROS (raw-buffer range check; soff is not part
-// of it).  That is the whole per-lane address arithmetic of an implicit-GEMM chunk: the (tap, cin-slice) offset is
-// one scalar, the pixel's offset a loop-invariant VGPR, an out-of-image tap the out-of-range constant.
-typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr unsigned kOobVoff = 0xFFFFFFF0u;
-__device__ __forceinline__ void blds16(v4i srd, unsigned voff, unsigned soff, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-               :
-               : "v"(voff), "s"(srd), "s"(soff), "s"(lds_dst)
-               : "memory");
-}
-__device__ __forceinline__ v4i make_srd(const void *base, unsigned bytes) {
-  const unsigned long long a = (unsigned long long)base;
-  v4i r;
-  r.x = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
-  r.y = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));   // stride 0, no swizzle
-  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-  r.w = 0x00020000;
-  return r;
-}
+// LDS-DMA primitives (glds16 / blds16 / make_srd / wait_vmcnt): csrc/dma.h
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, int VARIANT = 0>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvParams p, int ntiles, int mtiles) {
@@ -294,7 +261,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
 
   const float *__restrict__ in = p.in + (size_t)g * p.B * p.H * p.W * p.Cin;
   const float *__restrict__ w = p.w + (size_t)g * T * p.Cout * Kc;
-  const float *__restrict__ bias = p.bias + (size_t)g * p.Cout;
+  const float *__restrict__ bias = p.bias ? p.bias + (size_t)g * p.Cout : nullptr;
   const float *__restrict__ res = p.res ? p.res + (size_t)g * M * p.Cout : nullptr;
   float *__restrict__ out = p.out + (size_t)g * M * p.Cout;
   const float *zero = reinterpret_cast<const float *>(g_zero_page);
@@ -531,7 +498,7 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_glds_kernel(ConvPa
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int co = n0 + wn * WN + 16 * j + 4 * q;
-    const float4 bv = *reinterpret_cast<const float4 *>(bias + co);
+    const float4 bv = bias ? *reinterpret_cast<const float4 *>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + wm * WM + 16 * i + t;
@@ -563,7 +530,9 @@ static int launch_glds(const ConvParams &p, hipStream_t st, int kc) {
   const double flops = 2.0 * M * p.Cout * (STEM ? 3.0 : (double)p.Cin) * taps * p.G;
   const double bytes = 4.0 * p.G * ((double)p.B * p.H * p.W * (STEM ? 3 : p.Cin) + taps * p.Cout * (STEM ? 3 : p.Cin) +
                                     (double)M * p.Cout * (p.res ? 2 : 1));
-  ProfScope prof(kc, st, flops, bytes);
+  const ProfTag tag = {{p.prof_kc >= 0 ? p.prof_tag[0] : M, p.prof_kc >= 0 ? p.prof_tag[1] : p.Cin,
+                        p.prof_kc >= 0 ? p.prof_tag[2] : p.Cout, p.prof_kc >= 0 ? p.prof_tag[3] : p.dil}};
+  ProfScope prof(p.prof_kc >= 0 ? p.prof_kc : kc, st, p.prof_kc >= 0 ? p.prof_flops : flops, bytes, tag);
   const int mtiles = (M + BM - 1) / BM, ntiles = p.Cout / BN;
   const size_t lds = (size_t)3 * (BM + BN) * BK * sizeof(float);
   static DeviceOnce attr_set;
@@ -600,7 +569,9 @@ static int launch_cfg(const ConvParams &p, hipStream_t st, int kc) {
   const double flops = 2.0 * M * p.Cout * (STEM ? 3.0 : (double)p.Cin) * taps * p.G;
   const double bytes = 4.0 * p.G * ((double)p.B * p.H * p.W * (STEM ? 3 : p.Cin) + taps * p.Cout * (STEM ? 3 : p.Cin) +
                                     (double)M * p.Cout * (p.res ? 2 : 1));
-  ProfScope prof(kc, st, flops, bytes);
+  const ProfTag tag = {{p.prof_kc >= 0 ? p.prof_tag[0] : M, p.prof_kc >= 0 ? p.prof_tag[1] : p.Cin,
+                        p.prof_kc >= 0 ? p.prof_tag[2] : p.Cout, p.prof_kc >= 0 ? p.prof_tag[3] : p.dil}};
+  ProfScope prof(p.prof_kc >= 0 ? p.prof_kc : kc, st, p.prof_kc >= 0 ? p.prof_flops : flops, bytes, tag);
   const int mtiles = (M + BM - 1) / BM, ntiles = p.Cout / BN;
   const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
   static DeviceOnce attr_set;
@@ -830,7 +801,7 @@ static Choice choose(const ConvParams &p, hipStream_t st, int glds_default) {
 }
 
 int launch_conv(const ConvParams &p, hipStream_t st) {
-  UOC_REQUIRE(p.in && p.w && p.bias && p.out, "conv: null pointer");
+  UOC_REQUIRE(p.in && p.w && p.out && (p.bias || !p.stem), "conv: null pointer");
   UOC_REQUIRE(p.G >= 1 && p.B >= 1 && p.H >= 1 && p.W >= 1, "conv: bad shape");
   UOC_REQUIRE((long)p.B * p.H * p.W * p.Cin < (1l << 31) && (long)p.B * p.Ho * p.Wo * p.Cout < (1l << 31),
               "conv: tensor too large for 32-bit indexing");

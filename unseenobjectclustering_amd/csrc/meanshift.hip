@@ -416,20 +416,21 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
 // NH = 2 (128-d fields as two 64-channel planes): S sums over both halves; the accumulators of one block
 // cover ONE half (blockIdx.z), so S is computed twice — the price of keeping the 64-d register tiling.
 template <int ST, int NH>
-__global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__restrict__ X, int n,
+__global__ __launch_bounds__(HC_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void hc_iter_kernel(const float *__restrict__ X, int n,
                                                              const float *__restrict__ Z, int m, float kappa,
-                                                             float *__restrict__ partial) {
+                                                             float *__restrict__ partial_, int nvb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *Zs = smem;  // [NH][ST*16][ZP]; later reused as the cross-wave reduction buffer
   const int b = blockIdx.y;
-  const int nblk = gridDim.x;
+  const int nblk = nvb;                    // VIRTUAL blocks (hc_virtual_blocks: n only), walked by the physical ones
   const int hz = NH > 1 ? blockIdx.z : 0;  // the half this block accumulates
   X += (size_t)b * NH * n * C;
   Z += (size_t)b * NH * m * C;
-  partial += (((size_t)b * nblk + blockIdx.x) * NH + hz) * (ST * 16) * C;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = lane & 15, q = lane >> 4;
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+  float *partial = partial_ + (((size_t)b * nblk + vb) * NH + hz) * (ST * 16) * C;
 
   for (int i = tid; i < NH * ST * 16 * (C / 4); i += HC_THREADS) {
     const int h = i / (ST * 16 * (C / 4)), j = i % (ST * 16 * (C / 4));
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__rest
 
   const int ntile = (n + 15) >> 4;
   const int stride = nblk * (HC_THREADS / 64);
-  int tile = blockIdx.x * (HC_THREADS / 64) + wave;
+  int tile = vb * (HC_THREADS / 64) + wave;
 
   float4 xa[NH * 4], xb[4];
   auto load_tile = [&](int tl, float4(&a)[NH * 4], float4(&bb)[4]) {
@@ -558,6 +559,8 @@ __global__ __launch_bounds__(HC_THREADS) void hc_iter_kernel(const float *__rest
       }
     }
   }
+  __syncthreads();  // the next virtual block reloads the seeds into the buffer the reduction just used
+  }  // virtual blocks
 }
 
 // -------------------------------------------------------------------------------------------
@@ -757,61 +760,6 @@ __device__ __forceinline__ void hcr_run(const float *__restrict__ X, int n, cons
     for (int ct = 0; ct < 4; ++ct) red_wave[(s * 4 + ct) * 64 + lane] = acc[s][ct];
 }
 
-// EXPERIMENT KEPT FOR THE RECORD (UOC_HC_VARIANT=1; the shipped kernel is hc_iter_reg1_kernel below): block = 8 waves =
-// TWO per SIMD, on the hypothesis that the VALU work of one wave would run beside the MFMAs of the other.  Two waves
-// of ~330 registers do not fit a SIMD, so the SEEDS are split: waves 0-3 own seed tiles [0, ceil(ST/2)), waves 4-7 the
-// rest; waves w and w+4 (same SIMD) walk the same pixel tiles, each loading them itself.  Result: 87.5 vs 88.0 us —
-// no gain, and X is fetched twice (149 vs 85 MB per launch by the FETCH_SIZE counter).  The hypothesis is wrong on
-// gfx950: fp32 MFMA and VALU share the SIMD's fp32 lanes, so their issue is mutually exclusive no matter which wave
-// they come from (scripts/mfma_shadow.hip: MFMA + K v_fma = 35.5 + 2K cycles with one wave; with an MFMA-only and a
-// VALU-only wave on one SIMD the MFMA wave drops to 69 cycles per MFMA at K = 4).
-constexpr int HCR_THREADS = 512;
-constexpr int HCR_WPG = 4;  // waves per seed group
-
-template <int ST, int ABL = 0>
-__global__ __launch_bounds__(HCR_THREADS) void hc_iter_reg_kernel(const float *__restrict__ X, int n,
-                                                                  const float *__restrict__ Z, int m, float kappa,
-                                                                  float *__restrict__ partial) {
-  constexpr int STA = (ST + 1) / 2, STB = ST / 2;
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // only the cross-wave reduction of the epilogue
-  const int b = blockIdx.y;
-  const int nblk = gridDim.x;
-  X += (size_t)b * n * C;
-  Z += (size_t)b * m * C;
-  partial += ((size_t)b * nblk + blockIdx.x) * (ST * 16) * C;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int grp = wave / HCR_WPG, wg = wave % HCR_WPG;
-  const int t = lane & 15, q = lane >> 4;
-  const int stride = nblk * HCR_WPG;
-  const int tile = blockIdx.x * HCR_WPG + wg;
-  f32x4 *red = reinterpret_cast<f32x4 *>(smem);  // [8 waves][STA*4][64] f32x4
-  f32x4 *red_wave = red + (size_t)wave * STA * 4 * 64;
-  if (grp == 0) {
-    hcr_run<STA, ABL>(X, n, Z, m, 0, kappa, tile, stride, red_wave, lane);
-  } else if (STB > 0) {
-    hcr_run<(STB > 0 ? STB : 1), ABL>(X, n, Z, m, STA, kappa, tile, stride, red_wave, lane);
-  }
-  __syncthreads();
-  // ---- reduction: seed tile s of group g is summed over the group's four waves in the fixed order
-  // ((w0 + w1) + (w2 + w3)); the 8 waves share the ST tiles round-robin ----
-  for (int s = wave; s < ST; s += HCR_THREADS / 64) {
-    const int g = s < STA ? 0 : 1, sl = s - g * STA;
-    const f32x4 *base = red + (size_t)g * HCR_WPG * STA * 4 * 64;
-    f32x4 o[4];
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const f32x4 a0 = base[((0 * STA + sl) * 4 + ct) * 64 + lane], a1 = base[((1 * STA + sl) * 4 + ct) * 64 + lane];
-      const f32x4 a2 = base[((2 * STA + sl) * 4 + ct) * 64 + lane], a3 = base[((3 * STA + sl) * 4 + ct) * 64 + lane];
-      o[ct] = (a0 + a1) + (a2 + a3);
-    }
-    // lane (t,q) reg r holds newZ[seed 16s+4q+r][channel 4t+ct]
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      *reinterpret_cast<float4 *>(partial + (size_t)(16 * s + 4 * q + r) * C + 4 * t) =
-          make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
-  }
-}
-
 // THE SHIPPED KERNEL (UOC_HC_VARIANT=2, default): one wave per SIMD (4 waves per block, one block per CU), every wave
 // all ST seed tiles (~330 of its 512 registers), X read exactly once.  Cost model that fits the measurements: a pixel
 // tile costs 32 cycles per MFMA (224) + 2 per VALU (~230) + 8 per v_exp (28) + ~2.7 per MFMA->VALU switch, i.e. the
@@ -822,30 +770,36 @@ __global__ __launch_bounds__(HCR_THREADS) void hc_iter_reg_kernel(const float *_
 // +1.5 % — no gain (its 344 registers per lane leave room only for the smallest convolution tiles anyway); not kept.
 template <int ST, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void hc_iter_reg1_kernel(
-    const float *__restrict__ X, int n, const float *__restrict__ Z, int m, float kappa, float *__restrict__ partial) {
+    const float *__restrict__ X, int n, const float *__restrict__ Z, int m, float kappa, float *__restrict__ partial,
+    int nvb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int b = blockIdx.y;
-  const int nblk = gridDim.x;
   X += (size_t)b * n * C;
   Z += (size_t)b * m * C;
-  partial += ((size_t)b * nblk + blockIdx.x) * (ST * 16) * C;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = lane & 15, q = lane >> 4;
   f32x4 *red = reinterpret_cast<f32x4 *>(smem);  // [4 waves][ST*4][64] f32x4
-  hcr_run<ST, ABL>(X, n, Z, m, 0, kappa, blockIdx.x * 4 + wave, nblk * 4, red + (size_t)wave * ST * 4 * 64, lane);
-  __syncthreads();
-  for (int s = wave; s < ST; s += 4) {
-    f32x4 o[4];
+  // VIRTUAL blocks: the field is always cut into nvb blocks of 4 waves (nvb depends on n only, hc_virtual_blocks), and the
+  // launch's physical blocks walk them.  Which pixel tiles meet in which partial sum, and the order of every fp32
+  // addition, therefore do not depend on how many fields share the launch (batch), on the CU count or on the grid.
+  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    hcr_run<ST, ABL>(X, n, Z, m, 0, kappa, vb * 4 + wave, nvb * 4, red + (size_t)wave * ST * 4 * 64, lane);
+    __syncthreads();
+    float *dst = partial + ((size_t)b * nvb + vb) * (ST * 16) * C;
+    for (int s = wave; s < ST; s += 4) {
+      f32x4 o[4];
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-      const f32x4 a0 = red[((0 * ST + s) * 4 + ct) * 64 + lane], a1 = red[((1 * ST + s) * 4 + ct) * 64 + lane];
-      const f32x4 a2 = red[((2 * ST + s) * 4 + ct) * 64 + lane], a3 = red[((3 * ST + s) * 4 + ct) * 64 + lane];
-      o[ct] = (a0 + a1) + (a2 + a3);
+      for (int ct = 0; ct < 4; ++ct) {
+        const f32x4 a0 = red[((0 * ST + s) * 4 + ct) * 64 + lane], a1 = red[((1 * ST + s) * 4 + ct) * 64 + lane];
+        const f32x4 a2 = red[((2 * ST + s) * 4 + ct) * 64 + lane], a3 = red[((3 * ST + s) * 4 + ct) * 64 + lane];
+        o[ct] = (a0 + a1) + (a2 + a3);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float4 *>(dst + (size_t)(16 * s + 4 * q + r) * C + 4 * t) =
+            make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      *reinterpret_cast<float4 *>(partial + (size_t)(16 * s + 4 * q + r) * C + 4 * t) =
-          make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+    __syncthreads();  // the reduction buffer is written again by the next virtual block
   }
 }
 
@@ -1125,30 +1079,59 @@ struct MsWorkspace {
   size_t total;
 };
 
-// UOC_HC_VARIANT: 2 (default) = register-resident kernel, one wave per SIMD; 1 = register-resident, two waves per SIMD
-// with the seeds split between them; 0 = LDS-fragment kernel (the only one for 128-d fields)
+// UOC_HC_VARIANT: 2 (default) = register-resident kernel, one wave per SIMD; 0 = LDS-fragment kernel (the only one for
+// 128-d fields).  (1 was round 2's two-waves-per-SIMD experiment, measured equal and removed: DESIGN.md.)
 static int hc_variant() {
   static int v = -1;
   if (v < 0) {
     const char *e = getenv("UOC_HC_VARIANT");
     v = e ? atoi(e) : 2;
+    if (v != 0) v = 2;
   }
   return v;
 }
 
-static int hc_blocks(int batch, int n, int nh = 1, bool lds_kernel = false) {
+// Virtual blocks of a hill-climbing launch: a function of the field size ONLY (about 16 pixel tiles per wave, at most 256
+// blocks of 4 waves), so the fp32 summation order of the new seed positions is the same whether a field is clustered
+// alone, with three other frames or among 30 crops.  (Round 2 derived the block count from the batch: a frame's label
+// map could then depend on its launch-set mates.)
+static int hc_virtual_blocks(int n) {
   const int ntile = (n + 15) / 16;
-  // two 4-wave blocks per CU (253 registers => 2 waves/SIMD, 57 KB LDS each); more blocks only add
-  // prologue (Z -> LDS) / epilogue (partial reduce + 28 KB store) work and partial traffic
-  static int target = 0;
-  if (!target) {
-    const char *e = getenv("UOC_HC_BLOCKS");
-    target = e ? atoi(e) : 0;
-    if (target < 1) target = 0;
+  int nvb = (ntile + 63) / 64;
+  if (nvb > 256) nvb = 256;
+  if (nvb < 1) nvb = 1;
+  return nvb;
+}
+
+// Physical blocks per field: the count p that minimises (rounds of CUs the grid needs) x (virtual blocks per physical
+// block); one 4-wave block per CU (register-resident kernel) or two (LDS-fragment kernel).
+static int hc_physical_blocks(int batch, int nvb, int per_cu) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char *e = getenv("UOC_HC_BLOCKS");   // dev: physical blocks per field
+    forced = e ? atoi(e) : 0;
   }
-  // register-resident kernel: one 4-wave block per CU; LDS-fragment kernel: two
-  const int tgt = target ? target : ((!lds_kernel && nh == 1 && hc_variant() >= 1 && device_num_cu() > 0) ? device_num_cu() : 512);
-  int nblk = tgt / (batch > 0 ? batch : 1);
+  if (forced > 0) return forced < nvb ? forced : nvb;
+  const int slots = (device_num_cu() > 0 ? device_num_cu() : 256) * per_cu;
+  int best = 1;
+  long best_cost = -1;
+  for (int p = 1; p <= nvb; ++p) {
+    const long rounds = ((long)p * batch + slots - 1) / slots;
+    const long cost = rounds * ((nvb + p - 1) / p);
+    if (best_cost < 0 || cost <= best_cost) {   // ties: more (smaller) blocks
+      best_cost = cost;
+      best = p;
+    }
+  }
+  return best;
+}
+
+// grid of the per-pixel kernels that have no cross-pixel sums (assign): any block count gives the same result
+static int hc_blocks(int batch, int n, int nh = 1, bool lds_kernel = false) {
+  (void)nh;
+  (void)lds_kernel;
+  const int ntile = (n + 15) / 16;
+  int nblk = 512 / (batch > 0 ? batch : 1);
   if (nblk < 8) nblk = 8;
   const int maxb = (ntile + 3) / 4;
   if (nblk > maxb) nblk = maxb;
@@ -1165,7 +1148,7 @@ static MsWorkspace carve(void *base, int batch, int n, int nh = 1) {
     off += align_up(bytes, 256);
     return p;
   };
-  w.hc_nblk = hc_blocks(batch, n, nh);
+  w.hc_nblk = hc_virtual_blocks(n);
   w.dmin = (float *)take((size_t)batch * n * sizeof(float));
   w.part[0] = (ArgMax *)take((size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax));
   w.part[1] = (ArgMax *)take((size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax));
@@ -1217,6 +1200,12 @@ static int fps_persistent_plan(int batch, int n, int *bpi, int *nslots) {
   int ns = (per_block + FPP_THREADS - 1) / FPP_THREADS;  // pixels per lane
   if (ns > FPP_SLOTS) return 0;  // does not fit on chip: split the batch / use the streaming kernel
   if (ns < 1) ns = 1;
+  static int pack = -1;
+  if (pack < 0) {
+    const char *e = getenv("UOC_FPS_PACK");  // A/B: N = at least N pixels per lane, i.e. the grid on as few CUs as that allows
+    pack = e ? atoi(e) : 0;
+  }
+  if (pack > ns) ns = pack < FPP_SLOTS ? pack : FPP_SLOTS;
   b = (n + FPP_THREADS * ns - 1) / (FPP_THREADS * ns);  // drop blocks that would own no pixel
   *bpi = b;
   *nslots = ns;
@@ -1357,18 +1346,18 @@ static void launch_hc(const float *X, int batch, int n, float *Z, int m, float k
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set.mark();
   }
-  const bool reg = NH == 1 && hc_variant() >= 1;
-  const bool reg1 = hc_variant() == 2;   // one wave per SIMD
-  const size_t lds_reg = reg1 ? (size_t)4 * ST * 4 * 64 * sizeof(f32x4) : (size_t)8 * ((ST + 1) / 2) * 4 * 64 * sizeof(f32x4);
+  const bool reg = NH == 1 && hc_variant() == 2;   // register-resident kernel, one wave per SIMD
+  const size_t lds_reg = (size_t)4 * ST * 4 * 64 * sizeof(f32x4);
   if constexpr (NH == 1) {
     static DeviceOnce attr_reg;
     if (reg && !attr_reg.done() && lds_reg > 64 * 1024) {
-      (void)hipFuncSetAttribute(reg1 ? reinterpret_cast<const void *>(&hc_iter_reg1_kernel<ST>)
-                                     : reinterpret_cast<const void *>(&hc_iter_reg_kernel<ST>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hc_iter_reg1_kernel<ST>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
       attr_reg.mark();
     }
   }
+  const int nvb = w.hc_nblk;
+  const int phys = hc_physical_blocks(batch, nvb, reg ? 1 : 2);
   for (int it = 0; it < iters; ++it) {
     {
       // NH = 2 recomputes S for each half of the accumulators: (2 + 1) / 2 of the algorithmic flops per half
@@ -1376,26 +1365,29 @@ static void launch_hc(const float *X, int batch, int n, float *Z, int m, float k
                      4.0 * batch * ((double)n * C * NH + 2.0 * m * C * NH));
       if constexpr (NH == 1) {
         if (reg) {
+          const dim3 g(phys, batch), bdim(256);
+#ifdef UOC_DEV   // timing ablations of the ST = 7 kernel (wrong results): 1 = no exp arithmetic, 4 = S chains only, 5 = accumulate only
           static int abl = -1;
           if (abl < 0) {
-            const char *e = getenv("UOC_HC_ABLATE");  // dev only: timing ablations of the ST = 7 kernel
+            const char *e = getenv("UOC_HC_ABLATE");
             abl = e ? atoi(e) : 0;
+            if (abl) fprintf(stderr, "[uoc] UOC_HC_ABLATE=%d: hill climbing produces WRONG results (timing ablation)\n", abl);
           }
-          const dim3 g(w.hc_nblk, batch), bdim(reg1 ? 256 : HCR_THREADS);
-          auto go = [&](auto kern, bool set_attr) {
-            if (set_attr) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
-            hipLaunchKernelGGL(kern, g, bdim, lds_reg, st, X, n, Z, m, kappa, w.hc_partial);
+          auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+            hipLaunchKernelGGL(kern, g, bdim, lds_reg, st, X, n, Z, m, kappa, w.hc_partial, nvb);
           };
-          if (ST == 7 && abl == 1) go(hc_iter_reg_kernel<ST, (ST == 7 ? 1 : 0)>, true);
-          else if (ST == 7 && abl == 4) go(hc_iter_reg_kernel<ST, (ST == 7 ? 4 : 0)>, true);
-          else if (ST == 7 && abl == 5) go(hc_iter_reg_kernel<ST, (ST == 7 ? 5 : 0)>, true);
-          else if (reg1) go(hc_iter_reg1_kernel<ST, 0>, false);
-          else go(hc_iter_reg_kernel<ST, 0>, false);
+          if (ST == 7 && abl == 1) go(hc_iter_reg1_kernel<ST, (ST == 7 ? 1 : 0)>);
+          else if (ST == 7 && abl == 4) go(hc_iter_reg1_kernel<ST, (ST == 7 ? 4 : 0)>);
+          else if (ST == 7 && abl == 5) go(hc_iter_reg1_kernel<ST, (ST == 7 ? 5 : 0)>);
+          else
+#endif
+            hipLaunchKernelGGL((hc_iter_reg1_kernel<ST, 0>), g, bdim, lds_reg, st, X, n, Z, m, kappa, w.hc_partial, nvb);
         }
       }
       if (!reg)
-        hipLaunchKernelGGL((hc_iter_kernel<ST, NH>), dim3(w.hc_nblk, batch, NH), dim3(HC_THREADS), lds, st, X, n, Z, m,
-                           kappa, w.hc_partial);
+        hipLaunchKernelGGL((hc_iter_kernel<ST, NH>), dim3(phys, batch, NH), dim3(HC_THREADS), lds, st, X, n, Z, m,
+                           kappa, w.hc_partial, nvb);
     }
     ProfScope prof(KC_HC_FINALIZE, st, 0.0, 4.0 * batch * w.hc_nblk * NH * ST * 16.0 * C);
     hipLaunchKernelGGL(hc_finalize_kernel<NH>, dim3(m, batch), dim3(256), 0, st, w.hc_partial, w.hc_nblk, ST * 16, m, Z);

@@ -23,7 +23,8 @@ struct ConvLayer {
   int Cin, Cout, K, stride, dil, pad, relu;
   bool has_bn, has_bias, stem;
   float *d_w = nullptr, *d_b = nullptr;  // [G][...]
-  float *d_U = nullptr;                  // Winograd-transformed weights [G][16][Cin/32][Cout][32] (eligible layers only)
+  float *d_U = nullptr;                  // Winograd F(2x2) weights [G][16][Cin/32][Cout][32] (eligible layers, wino_f == 2)
+  float *d_U4 = nullptr;                 // Winograd F(4x4) weights [G*36][Cout][Cin] (eligible layers, wino_f == 4)
   size_t w_per_group = 0;
 };
 
@@ -40,7 +41,8 @@ struct uoc_net {
   int stem = -1, fc = -1;
   bool finalized = false;
   int device = -1;
-  int wino_min_cin = 128;  // 3x3 stride-1 layers with Cin >= this run as Winograd F(2x2,3x3); 0 = never
+  int wino_min_cin = 128;  // 3x3 stride-1 layers with Cin >= this run as Winograd convolutions; 0 = never
+  int wino_f = 4;          // output tile of the Winograd path: 4 = F(4x4,3x3) (csrc/wino4.hip), 2 = F(2x2,3x3) (csrc/wino.hip)
   int mode = UOC_NET_RGBD_ADD;
   int G = 2;  // backbones evaluated side by side (2 for RGBD 'add' and 'cat')
 };
@@ -171,8 +173,13 @@ static int finalize_layer(uoc_net *n, ConvLayer &L) {
   // Static, not autotuned: the two algorithms round differently, and results must not depend on timing.
   if (!L.stem && L.K == 3 && L.stride == 1 && n->wino_min_cin > 0 && L.Cin >= n->wino_min_cin && L.Cin % 32 == 0 &&
       L.Cout % 64 == 0) {
-    UOC_HIP_CHECK(hipMalloc(&L.d_U, (size_t)G * 16 * L.Cout * L.Cin * sizeof(float)));
-    if (int rc = launch_wino_weights(L.d_w, L.d_U, G, L.Cout, L.Cin, nullptr)) return rc;
+    if (n->wino_f == 4) {
+      UOC_HIP_CHECK(hipMalloc(&L.d_U4, (size_t)G * 36 * L.Cout * L.Cin * sizeof(float)));
+      if (int rc = launch_wino4_weights(L.d_w, L.d_U4, G, L.Cout, L.Cin, nullptr)) return rc;
+    } else {
+      UOC_HIP_CHECK(hipMalloc(&L.d_U, (size_t)G * 16 * L.Cout * L.Cin * sizeof(float)));
+      if (int rc = launch_wino_weights(L.d_w, L.d_U, G, L.Cout, L.Cin, nullptr)) return rc;
+    }
     UOC_HIP_CHECK(hipDeviceSynchronize());
   }
   return UOC_OK;
@@ -196,7 +203,7 @@ struct NetWs {
   float *in4, *stem, *stem_part, *buf[4], *fc, *wino;
   size_t total;
 };
-static NetWs carve_net(void *base, int mode, int B, int H, int W) {
+static NetWs carve_net(void *base, int mode, int wino_f, int B, int H, int W) {
   const Dims d = dims(H, W);
   const int G = (mode == UOC_NET_RGBD_ADD || mode == UOC_NET_RGBD_CAT) ? 2 : 1;
   const int n_in = (G == 2 || mode == UOC_NET_RGBD_EARLY) ? 2 : 1;
@@ -223,6 +230,14 @@ static NetWs carve_net(void *base, int mode, int B, int H, int W) {
   if (wv3 > wv) wv = wv3;
   if (wv2 > wv) wv = wv2;
   if (wv1 > wv) wv = wv1;
+  if (wino_f == 4) {  // F(4x4): V and M frequency planes [G*36][tiles][Cin + Cout]
+    wv = 0;
+    const int cand[6][4] = {{3, 4, 512, 512}, {3, 4, 256, 512}, {3, 2, 256, 256}, {3, 2, 128, 256}, {3, 1, 128, 128}, {2, 1, 64, 64}};
+    for (const auto &c : cand) {
+      const size_t v = wino4_ws_floats(G, B, c[0] == 3 ? d.H3 : d.H2, c[0] == 3 ? d.W3 : d.W2, c[1], c[2], c[3]);
+      if (v > wv) wv = v;
+    }
+  }
   w.wino = take(wv);
   w.total = off;
   return w;
@@ -250,6 +265,7 @@ static int run_conv(int G, const ConvLayer &L, const float *in, const float *res
   p.pad = L.pad;
   p.relu = L.relu;
   p.stem = L.stem ? 1 : 0;
+  if (L.d_U4 && wino_ws && wino4_eligible(p)) return launch_wino4_conv(p, L.d_U4, wino_ws, st);
   if (L.d_U && wino_ws && wino_eligible(p)) return launch_wino_conv(p, L.d_U, wino_ws, st);
   return launch_conv(p, st);
 }
@@ -274,6 +290,7 @@ int uoc_net_create_mode(uoc_net **out, int mode) {
   n->G = (mode == UOC_NET_RGBD_ADD || mode == UOC_NET_RGBD_CAT) ? 2 : 1;
   build_graph(n);
   if (const char *e = getenv("UOC_WINOGRAD_MIN_CIN")) n->wino_min_cin = atoi(e);  // 0 disables the Winograd path
+  if (const char *e = getenv("UOC_WINOGRAD_F")) n->wino_f = atoi(e) == 2 ? 2 : 4;     // A/B: the F(2x2,3x3) kernels of round 1-2
   *out = n;
   return UOC_OK;
 }
@@ -286,6 +303,7 @@ int uoc_net_destroy(uoc_net *n) {
     if (L.d_w) (void)hipFree(L.d_w);
     if (L.d_b) (void)hipFree(L.d_b);
     if (L.d_U) (void)hipFree(L.d_U);
+    if (L.d_U4) (void)hipFree(L.d_U4);
   }
   delete n;
   return UOC_OK;
@@ -311,7 +329,7 @@ int uoc_net_finalize(uoc_net *n) {
 
 size_t uoc_net_workspace_bytes(const uoc_net *n, int B, int H, int W) {
   if (!n || B < 1 || H < 8 || W < 8) return 0;
-  return carve_net(nullptr, n->mode, B, H, W).total;
+  return carve_net(nullptr, n->mode, n->wino_f, B, H, W).total;
 }
 
 int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, int H, int W, float *d_embed,
@@ -321,7 +339,7 @@ int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, i
               "null tensor pointer");
   UOC_REQUIRE(B >= 1 && H >= 8 && W >= 8, "bad input shape B=%d H=%d W=%d", B, H, W);
   const int G = n->G;
-  const NetWs w = carve_net(d_ws, n->mode, B, H, W);
+  const NetWs w = carve_net(d_ws, n->mode, n->wino_f, B, H, W);
   UOC_REQUIRE(d_ws && ws_bytes >= w.total && ((uintptr_t)d_ws & 255) == 0, "workspace too small or misaligned (%zu < %zu)",
               ws_bytes, w.total);
   hipStream_t st = (hipStream_t)stream;
@@ -399,7 +417,28 @@ int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, co
   p.stem = 0;
   p.Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   p.Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
-  const char *force = getenv("UOC_CONV_WINOGRAD");  // test / micro-benchmark hook: 1 = Winograd for eligible shapes
+  const char *force = getenv("UOC_CONV_WINOGRAD");  // test / micro-benchmark hook: 1 = Winograd F(2x2), 4 = F(4x4) for eligible shapes
+  if (force && atoi(force) == 4 && wino4_eligible(p)) {
+    static float *U4 = nullptr, *ws4 = nullptr;
+    static size_t ucap4 = 0, wcap4 = 0;
+    static const float *u4_for = nullptr;
+    const size_t un = (size_t)G * 36 * Cout * Cin, wn = wino4_ws_floats(G, B, H, W, dil, Cin, Cout);
+    hipStream_t st = (hipStream_t)stream;
+    if (un > ucap4) {
+      if (U4) (void)hipFree(U4);
+      UOC_HIP_CHECK(hipMalloc(&U4, un * sizeof(float)));
+      ucap4 = un;
+      u4_for = nullptr;
+    }
+    if (wn > wcap4) {
+      if (ws4) (void)hipFree(ws4);
+      UOC_HIP_CHECK(hipMalloc(&ws4, wn * sizeof(float)));
+      wcap4 = wn;
+    }
+    (void)u4_for;   // always re-transform: callers reuse device addresses with new weights
+    if (int rc = launch_wino4_weights(d_w, U4, G, Cout, Cin, st)) return rc;
+    return launch_wino4_conv(p, U4, ws4, st);
+  }
   if (force && atoi(force) == 1 && wino_eligible(p)) {
     // scratch owned by this entry (kept between calls; the network path gets its scratch from the caller)
     static float *U = nullptr, *V = nullptr;

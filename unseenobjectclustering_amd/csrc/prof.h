@@ -28,18 +28,27 @@ enum KernelClass {
   KC_ASSIGN,
   KC_RELABEL,
   KC_ROI,
+  KC_WINO4_INPUT,
+  KC_WINO4_GEMM,
+  KC_WINO4_OUTPUT,
   KC_COUNT
 };
 
+// Optional launch-shape tag: the report also aggregates per (class, tag), so that one kernel class can be broken down
+// by layer shape (convolutions: rows M of the GEMM, Cin, Cout, dilation).
+struct ProfTag {
+  int v[4] = {0, 0, 0, 0};
+};
+
 extern bool g_prof_enabled;
-void prof_begin(int kc, hipStream_t st, double flops, double bytes);
+void prof_begin(int kc, hipStream_t st, double flops, double bytes, const ProfTag &tag);
 void prof_end(hipStream_t st);
 
 struct ProfScope {
   hipStream_t st;
   bool on;
-  ProfScope(int kc, hipStream_t s, double flops, double bytes) : st(s), on(g_prof_enabled) {
-    if (on) prof_begin(kc, s, flops, bytes);
+  ProfScope(int kc, hipStream_t s, double flops, double bytes, const ProfTag &tag = ProfTag()) : st(s), on(g_prof_enabled) {
+    if (on) prof_begin(kc, s, flops, bytes, tag);
   }
   ~ProfScope() {
     if (on) prof_end(st);

@@ -472,7 +472,8 @@ int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_
   UOC_REQUIRE(U && Vws, "winograd: null weight/workspace pointer");
   const WinoGeom geo = make_geom(p.B, p.H, p.W, p.dil);
   {
-    ProfScope prof(KC_WINO_INPUT, st, 0.0, 4.0 * p.G * ((double)p.B * p.H * p.W * p.Cin + 16.0 * geo.NT * p.Cin));
+    ProfScope prof(KC_WINO_INPUT, st, 0.0, 4.0 * p.G * ((double)p.B * p.H * p.W * p.Cin + 16.0 * geo.NT * p.Cin),
+                   ProfTag{{geo.NT, p.Cin, p.Cout, p.dil}});
     const long total = (long)p.G * geo.NT * (p.Cin / 4);
     long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
@@ -494,7 +495,8 @@ int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_
   }
   const double M = (double)p.B * p.H * p.W;
   ProfScope prof(KC_WINO_GEMM, st, 2.0 * M * p.Cout * p.Cin * 9.0 * p.G,
-                 4.0 * p.G * (16.0 * geo.NT * p.Cin + 16.0 * p.Cout * p.Cin + M * p.Cout * (p.res ? 2 : 1)));
+                 4.0 * p.G * (16.0 * geo.NT * p.Cin + 16.0 * p.Cout * p.Cin + M * p.Cout * (p.res ? 2 : 1)),
+                 ProfTag{{geo.NT, p.Cin, p.Cout, p.dil}});
   if (const char *e = getenv("UOC_WINO_TMT")) {  // dev: force the tile height
     const int v = atoi(e);
     if (v >= 2 && v <= 7) best = v;

@@ -1,0 +1,185 @@
+// Winograd F(4x4, 3x3) transforms: geometry and the three small matrix products, written as host + device inline
+// functions so that tests/csrc/wino4_host_test.cpp can run the very same arithmetic on the CPU against a direct
+// convolution (no GPU in the build container).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      4x4 outputs from a 6x6 input patch, 36 products per (cin, cout)
+//                                              instead of the direct form's 144: 4x fewer matrix-core flops
+//
+// Interpolation points (0, 1, -1, 2, -1/2, inf).  The textbook set (0, +-1, +-2) and three others were compared on
+// the CPU through the whole two-branch network (scripts/wino_f4_error.py, calibrated weights, 480x640): embeddings
+// differ from an fp64 evaluation by 1.16e-8 on average with this set against 1.05e-8 for F(2x2,3x3), 1.25e-8 for the
+// textbook F(4x4) set and ~1.0e-8 for the direct fp32 sum; the largest difference to the direct fp32 result is 8.8e-7
+// (F(2x2): 6.6e-7).  B^T and A^T contain only binary fractions (exact multiplications, the additions round); G has
+// thirds and fifteenths and is applied once, in double, when the weights are loaded.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace uoc {
+
+struct Wino4Geom {
+  int B, H, W, d, TH, TW, NT;  // TH x TW tiles of 4x4 outputs per (image, dilation phase); NT = B*d*d*TH*TW
+};
+
+__host__ __device__ inline Wino4Geom make_geom4(int B, int H, int W, int d) {
+  Wino4Geom g;
+  g.B = B;
+  g.H = H;
+  g.W = W;
+  g.d = d;
+  g.TH = ((H + d - 1) / d + 3) / 4;
+  g.TW = ((W + d - 1) / d + 3) / 4;
+  g.NT = B * d * d * g.TH * g.TW;
+  return g;
+}
+
+// tile index -> image and the first output pixel of the tile; outputs are (oy + a*d, ox + e*d), a, e in 0..3, the
+// input patch is (oy + (i-1)*d, ox + (j-1)*d), i, j in 0..5 (dilation by phase decomposition as in csrc/wino.hip)
+__host__ __device__ inline void wino4_decode(int tau, const Wino4Geom &g, int &b, int &oy, int &ox) {
+  const int tx = tau % g.TW;
+  tau /= g.TW;
+  const int ty = tau % g.TH;
+  tau /= g.TH;
+  const int px = tau % g.d;
+  tau /= g.d;
+  const int py = tau % g.d;
+  b = tau / g.d;
+  oy = py + 4 * ty * g.d;
+  ox = px + 4 * tx * g.d;
+}
+
+// ---- scalar / float4 arithmetic used by the templates below ----------------------------------------------------
+__host__ __device__ inline float w4_fma(float c, float a, float b) { return fmaf(c, a, b); }
+__host__ __device__ inline float w4_add(float a, float b) { return a + b; }
+__host__ __device__ inline float w4_sub(float a, float b) { return a - b; }
+__host__ __device__ inline float w4_neg(float a) { return -a; }
+__host__ __device__ inline float4 w4_fma(float c, float4 a, float4 b) {
+  return make_float4(fmaf(c, a.x, b.x), fmaf(c, a.y, b.y), fmaf(c, a.z, b.z), fmaf(c, a.w, b.w));
+}
+__host__ __device__ inline float4 w4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__host__ __device__ inline float4 w4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__host__ __device__ inline float4 w4_neg(float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
+
+// o = B^T i,   B^T = [[1, 1.5, -2, -1.5, 1, 0], [0, -1, -2.5, -0.5, 1, 0], [0, 1, 0.5, -2.5, 1, 0],
+//                     [0, -0.5, -1, 0.5, 1, 0], [0, 2, -1, -2, 1, 0],      [0, 1, 1.5, -2, -1.5, 1]]
+template <typename T>
+__host__ __device__ inline void wino4_bt(const T (&i)[6], T (&o)[6]) {
+  o[0] = w4_fma(-1.5f, i[3], w4_fma(-2.0f, i[2], w4_fma(1.5f, i[1], w4_add(i[0], i[4]))));
+  o[1] = w4_fma(-0.5f, i[3], w4_fma(-2.5f, i[2], w4_sub(i[4], i[1])));
+  o[2] = w4_fma(-2.5f, i[3], w4_fma(0.5f, i[2], w4_add(i[4], i[1])));
+  o[3] = w4_fma(0.5f, i[3], w4_fma(-0.5f, i[1], w4_sub(i[4], i[2])));
+  o[4] = w4_fma(-2.0f, i[3], w4_fma(2.0f, i[1], w4_sub(i[4], i[2])));
+  o[5] = w4_fma(-1.5f, i[4], w4_fma(-2.0f, i[3], w4_fma(1.5f, i[2], w4_add(i[1], i[5]))));
+}
+
+// y = A^T m,   A^T = [[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -0.5, 0], [0, 1, 1, 4, 0.25, 0], [0, 1, -1, 8, -0.125, 1]]
+template <typename T>
+__host__ __device__ inline void wino4_at(const T (&m)[6], T (&y)[4]) {
+  const T s12 = w4_add(m[1], m[2]), d12 = w4_sub(m[1], m[2]);
+  y[0] = w4_add(w4_add(m[0], s12), w4_add(m[3], m[4]));
+  y[1] = w4_fma(-0.5f, m[4], w4_fma(2.0f, m[3], d12));
+  y[2] = w4_fma(0.25f, m[4], w4_fma(4.0f, m[3], s12));
+  y[3] = w4_add(w4_fma(-0.125f, m[4], w4_fma(8.0f, m[3], d12)), m[5]);
+}
+
+// u = G k (double),   G = [[1, 0, 0], [-1/3, -1/3, -1/3], [1/3, -1/3, 1/3], [1/15, 2/15, 4/15], [-16/15, 8/15, -4/15], [0, 0, 1]]
+__host__ __device__ inline void wino4_g(const double (&k)[3], double (&u)[6]) {
+  u[0] = k[0];
+  u[1] = -(k[0] + k[1] + k[2]) / 3.0;
+  u[2] = (k[0] - k[1] + k[2]) / 3.0;
+  u[3] = (k[0] + 2.0 * k[1] + 4.0 * k[2]) / 15.0;
+  u[4] = (-16.0 * k[0] + 8.0 * k[1] - 4.0 * k[2]) / 15.0;
+  u[5] = k[2];
+}
+
+// ---- per-element bodies of the three elementwise kernels (one (group, tile / weight, channel quad) each) --------
+
+// U[(g*36 + xi)][cout][cin] = (G g G^T)[xi] from w [g][9][cout][cin]; one (g, cout, cin) per call
+__host__ __device__ inline void wino4_weight_body(const float *w, float *U, int G, int Cout, int Cin, int g, int co, int ci) {
+  double t[6][3];
+  for (int b = 0; b < 3; ++b) {
+    const double col[3] = {(double)w[(((size_t)g * 9 + 0 + b) * Cout + co) * Cin + ci],
+                           (double)w[(((size_t)g * 9 + 3 + b) * Cout + co) * Cin + ci],
+                           (double)w[(((size_t)g * 9 + 6 + b) * Cout + co) * Cin + ci]};
+    double u[6];
+    wino4_g(col, u);
+    for (int i = 0; i < 6; ++i) t[i][b] = u[i];
+  }
+  const size_t plane = (size_t)Cout * Cin;
+  for (int i = 0; i < 6; ++i) {
+    double u[6];
+    wino4_g(t[i], u);
+    for (int j = 0; j < 6; ++j) U[((size_t)g * 36 + 6 * i + j) * plane + (size_t)co * Cin + ci] = (float)u[j];
+  }
+  (void)G;
+}
+
+// V[(g*36 + xi)][tile][cin] = (B^T d B)[xi] for channels 4*c4 .. 4*c4+3 of tile tau; in: [g][B][H][W][C]
+__host__ __device__ inline void wino4_input_body(const float *in, float *V, const Wino4Geom &geo, int C, int g, int tau, int c4) {
+  int b, oy, ox;
+  wino4_decode(tau, geo, b, oy, ox);
+  const float *src = in + (((size_t)g * geo.B + b) * geo.H * geo.W) * C + 4 * c4;
+  float4 t[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int x = ox + (j - 1) * geo.d;
+    float4 col[6], o[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int y = oy + (i - 1) * geo.d;
+      const bool ok = (unsigned)y < (unsigned)geo.H && (unsigned)x < (unsigned)geo.W;
+      col[i] = ok ? *reinterpret_cast<const float4 *>(src + ((size_t)y * geo.W + x) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    wino4_bt(col, o);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+  }
+  const size_t plane = (size_t)geo.NT * C;
+  float *dst = V + (size_t)g * 36 * plane + (size_t)tau * C + 4 * c4;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float4 o[6];
+    wino4_bt(t[i], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<float4 *>(dst + (size_t)(6 * i + j) * plane) = o[j];
+  }
+}
+
+// out[g][b][y][x][cout] = relu?(A^T M A + bias (+ res)) for channels 4*c4 .. of tile tau; M: [(g*36 + xi)][tile][cout]
+__host__ __device__ inline void wino4_output_body(const float *M, const float *bias, const float *res, float *out,
+                                                  const Wino4Geom &geo, int Cout, int relu, int g, int tau, int c4) {
+  const size_t plane = (size_t)geo.NT * Cout;
+  const float *src = M + (size_t)g * 36 * plane + (size_t)tau * Cout + 4 * c4;
+  float4 s[4][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float4 col[6], o[4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const float4 *>(src + (size_t)(6 * i + j) * plane);
+    wino4_at(col, o);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) s[a][j] = o[a];
+  }
+  int b, oy, ox;
+  wino4_decode(tau, geo, b, oy, ox);
+  const size_t gsz = (size_t)geo.B * geo.H * geo.W * Cout;
+  const float4 bv = *reinterpret_cast<const float4 *>(bias + (size_t)g * Cout + 4 * c4);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    float4 yv[4];
+    wino4_at(s[a], yv);
+    const int y = oy + a * geo.d;
+    if (y >= geo.H) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int x = ox + e * geo.d;
+      if (x >= geo.W) continue;
+      const size_t o = (size_t)g * gsz + (((size_t)b * geo.H + y) * geo.W + x) * Cout + 4 * c4;
+      float4 v = w4_add(yv[e], bv);
+      if (res) v = w4_add(v, *reinterpret_cast<const float4 *>(res + o));
+      if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+      *reinterpret_cast<float4 *>(out + o) = v;
+    }
+  }
+}
+
+}  // namespace uoc
