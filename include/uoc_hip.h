@@ -197,6 +197,11 @@ int uoc_roi_match_stats(const int32_t *d_labels_crop, const float *d_mask_crops,
 int uoc_roi_paste(const int32_t *d_labels_crop, const uoc_roi_table *d_table, const int32_t *d_map,
                   const int32_t *d_order, int K, int S, int H, int W, int32_t *d_refined, void *stream);
 
+/* Frame-parallel runner (no reference counterpart; SURVEY 8(e): the gathered block is uint8 like the ROS consumer's cast,
+ * ros/test_images_segmentation.py:165): d_out[i] = (uint8) d_labels[i] for i < n, *d_top = max(*d_top, max_i d_labels[i])
+ * (the caller checks once per block that no id exceeded 255). */
+int uoc_labels_to_u8(const int32_t *d_labels, long n, uint8_t *d_out, int32_t *d_top, void *stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Evaluation — the integer statistics of multilabel_metrics (lib/utils/evaluation.py:109-257; overlap and

@@ -68,7 +68,8 @@ def _declare(lib):
     lib.uoc_roi_crop.argtypes = [P, P, P, c_int, c_int, P, c_int, c_int, P, P, P, P]
     lib.uoc_roi_match_stats.argtypes = [P, P, P, c_int, c_int, P, P, P, c_size_t, P]
     lib.uoc_roi_paste.argtypes = [P, P, P, P, c_int, c_int, c_int, c_int, P, P]
-    for name in ("uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats", "uoc_roi_paste"):
+    lib.uoc_labels_to_u8.argtypes = [P, ctypes.c_long, P, P, P]
+    for name in ("uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats", "uoc_roi_paste", "uoc_labels_to_u8"):
         getattr(lib, name).restype = c_int
     lib.uoc_lzf_decompress.argtypes = [P, c_size_t, P, c_size_t]
     lib.uoc_lzf_decompress.restype = ctypes.c_long
@@ -90,7 +91,7 @@ EXPORTED_SYMBOLS = (
     "uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",
     "uoc_net_forward", "uoc_conv2d_nhwc",
     "uoc_roi_workspace_bytes", "uoc_prep_rgbd", "uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats",
-    "uoc_roi_paste", "uoc_eval_workspace_bytes", "uoc_eval_pair_stats", "uoc_lzf_decompress", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
+    "uoc_roi_paste", "uoc_labels_to_u8", "uoc_eval_workspace_bytes", "uoc_eval_pair_stats", "uoc_lzf_decompress", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
 )
 
 

@@ -23,8 +23,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // The same through a raw buffer descriptor: address = descriptor base + soff (wave-uniform SGPR) + voff (per lane);
-// a lane whose voff lies beyond the descriptor's num_records delivers ZEROS (raw-buffer range check; soff is not part
-// of it).  That is the whole per-lane address arithmetic of an implicit-GEMM chunk: the (tap, cin-slice) offset is
+// a lane whose voff lies beyond the descriptor's num_records delivers ZEROS (raw-buffer range check).  Measured on gfx950
+// (round 3, csrc/wino4.hip): the check covers voff + soff, so a descriptor must span everything soff can reach.  That is the whole per-lane address arithmetic of an implicit-GEMM chunk: the (tap, cin-slice) offset is
 // one scalar, the pixel's offset a loop-invariant VGPR, an out-of-image tap the out-of-range constant.
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr unsigned kOobVoff = 0xFFFFFFF0u;

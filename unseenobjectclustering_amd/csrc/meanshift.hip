@@ -680,28 +680,51 @@ __device__ __forceinline__ void hcr_tile(const float4 (&xa)[4], const float4 (&x
   hcr_tile_steps<ST, ABL>(xa, xb, zb, acc, kappa, std::make_integer_sequence<int, ST + 2>{});
 }
 
-// The work of one wave: seed tiles [T0, T0 + NT) against the wave's pixel tiles; leaves its 4*NT accumulator
-// registers in LDS for the block's reduction.
-template <int NT, int ABL>
-__device__ __forceinline__ void hcr_run(const float *__restrict__ X, int n, const float *__restrict__ Z, int m, int T0,
-                                        float kappa, int tile, int stride, f32x4 *red_wave, int lane) {
+// THE SHIPPED KERNEL (UOC_HC_VARIANT=2, default): one wave per SIMD (4 waves per block, one block per CU), every wave
+// all ST seed tiles (~330 of its 512 registers), X read exactly once.  Cost model that fits the measurements: a pixel
+// tile costs 32 cycles per MFMA (224) + 2 per VALU (~230) + 8 per v_exp (28) + ~2.7 per MFMA->VALU switch, i.e. the
+// floor of this formulation is ~8 000 cycles per tile against 7 168 of pure MFMA.
+// The 112 KB of LDS serve the cross-wave reductions only.
+//
+// VIRTUAL blocks: the field is always cut into nvb blocks of 4 waves (nvb depends on n only, hc_virtual_blocks), and the
+// launch's physical blocks walk them.  Which pixel tiles meet in which partial sum, and the order of every fp32
+// addition, therefore do not depend on how many fields share the launch (batch), on the CU count or on the grid.
+// The walk is ONE software pipeline: the seed fragments are loaded once, and the first tile of the next virtual block
+// is already in flight while the current one is reduced through LDS and stored (per virtual block that leaves the
+// reduction itself, ~2 us against ~70 us of tiles).
+// (Round 2's two-waves-per-SIMD variant with the seeds split between the waves measured the same 87.5 vs 88.0 us and
+// fetched X twice; it was removed in round 3 — fp32 MFMA and VALU share the SIMD's lanes, DESIGN.md.)
+template <int ST, int ABL = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void hc_iter_reg1_kernel(
+    const float *__restrict__ X, int n, const float *__restrict__ Z, int m, float kappa, float *__restrict__ partial,
+    int nvb) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int b = blockIdx.y;
+  X += (size_t)b * n * C;
+  Z += (size_t)b * m * C;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int t = lane & 15, q = lane >> 4;
-  // seed fragments: zb[i][v] = Z[seed 16(T0+i)+t][16v+4q .. +3]  (B operand of S^T = X Z^T), zero rows beyond m.
+  f32x4 *red = reinterpret_cast<f32x4 *>(smem);  // [4 waves][ST*4][64] f32x4
+  f32x4 *red_wave = red + (size_t)wave * ST * 4 * 64;
+
+  // seed fragments: zb[i][v] = Z[seed 16i+t][16v+4q .. +3]  (B operand of S^T = X Z^T), zero rows beyond m.
   // Unconditional loads from a clamped row + a select later: a predicated load would get its own branch and its own
-  // s_waitcnt vmcnt(0), i.e. NT serialised memory latencies in the prologue.
-  float4 zb[NT][4];
+  // s_waitcnt vmcnt(0), i.e. ST serialised memory latencies in the prologue.
+  float4 zb[ST][4];
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < ST; ++i)
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-      zb[i][v] = *reinterpret_cast<const float4 *>(Z + (size_t)min(16 * (T0 + i) + t, m - 1) * C + 16 * v + 4 * q);
-  f32x4 acc[NT][4];
+      zb[i][v] = *reinterpret_cast<const float4 *>(Z + (size_t)min(16 * i + t, m - 1) * C + 16 * v + 4 * q);
+  f32x4 acc[ST][4];
 #pragma unroll
-  for (int s = 0; s < NT; ++s)
+  for (int s = 0; s < ST; ++s)
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) acc[s][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int ntile = (n + 15) >> 4;
+  const int stride = nvb * 4;
   // Pixel tiles: branch-free loads (clamped row index).  A clamped xa row only produces a finite S / W for a pixel
   // whose xb row is zeroed, so out-of-range pixels contribute exactly 0; xb is zeroed only in the (rare) partial tile.
   auto load_tile = [&](int tl, float4(&a)[4], float4(&bb)[4]) {
@@ -724,66 +747,49 @@ __device__ __forceinline__ void hcr_run(const float *__restrict__ X, int n, cons
         if (base + 4 * q + r >= n) bb[r] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
+  int vb = blockIdx.x;
+  int held = vb * 4 + wave;   // the tile whose pixels sit in xa / xb
   float4 xa[4], xb[4];
-  load_tile(tile, xa, xb);
-  mask_tile(tile, xb);
+  load_tile(held, xa, xb);
+  mask_tile(held, xb);
 #pragma unroll
-  for (int i = 0; i < NT; ++i)
+  for (int i = 0; i < ST; ++i)
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-      if (16 * (T0 + i) + t >= m) zb[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (16 * i + t >= m) zb[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  // The loads of the wave's NEXT tile are issued before the current tile's MFMAs and first read after them.
-  // hipcc undoes a plain `xa = na` double buffer (it coalesces the copy, rotates the loop and ends up with
-  // load-then-wait at the top of every tile, ~0.8 us exposed per tile) and sinks the loads of a two-body ping-pong
-  // loop into the second body — so the hand-over is 32 opaque v_mov and a sched_barrier keeps the loads above the
-  // first MFMA.
-  for (; tile < ntile; tile += stride) {
-    float4 na[4], nb[4];
-    load_tile(tile + stride, na, nb);
-    __builtin_amdgcn_sched_barrier(0);
-    hcr_tile<NT, ABL>(xa, xb, zb, acc, kappa);
+  while (vb < nvb) {
+    // The loads of the wave's NEXT tile (the first tile of the next virtual block behind the last one of this block)
+    // are issued before the current tile's MFMAs and first read after them.  hipcc undoes a plain `xa = na` double
+    // buffer (it coalesces the copy, rotates the loop and ends up with load-then-wait at the top of every tile, ~0.8 us
+    // exposed per tile) and sinks the loads of a two-body ping-pong loop into the second body — so the hand-over is 32
+    // opaque v_mov and a sched_barrier keeps the loads above the first MFMA.
+    for (int tile = vb * 4 + wave; tile < ntile; tile += stride) {   // invariant: held == tile
+      const int nxt = tile + stride < ntile ? tile + stride : (vb + (int)gridDim.x) * 4 + wave;
+      float4 na[4], nb[4];
+      load_tile(nxt, na, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      hcr_tile<ST, ABL>(xa, xb, zb, acc, kappa);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                   : "=&v"(xa[v].x), "=&v"(xa[v].y), "=&v"(xa[v].z), "=&v"(xa[v].w)
-                   : "v"(na[v].x), "v"(na[v].y), "v"(na[v].z), "v"(na[v].w));
-      asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                   : "=&v"(xb[v].x), "=&v"(xb[v].y), "=&v"(xb[v].z), "=&v"(xb[v].w)
-                   : "v"(nb[v].x), "v"(nb[v].y), "v"(nb[v].z), "v"(nb[v].w));
+      for (int v = 0; v < 4; ++v) {
+        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                     : "=&v"(xa[v].x), "=&v"(xa[v].y), "=&v"(xa[v].z), "=&v"(xa[v].w)
+                     : "v"(na[v].x), "v"(na[v].y), "v"(na[v].z), "v"(na[v].w));
+        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                     : "=&v"(xb[v].x), "=&v"(xb[v].y), "=&v"(xb[v].z), "=&v"(xb[v].w)
+                     : "v"(nb[v].x), "v"(nb[v].y), "v"(nb[v].z), "v"(nb[v].w));
+      }
+      mask_tile(nxt, xb);
+      held = nxt;
     }
-    mask_tile(tile + stride, xb);
-  }
+    // ---- this virtual block is complete: the four waves' accumulators meet in LDS, (w0 + w1) + (w2 + w3) ----
 #pragma unroll
-  for (int s = 0; s < NT; ++s)
+    for (int s = 0; s < ST; ++s)
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct) red_wave[(s * 4 + ct) * 64 + lane] = acc[s][ct];
-}
-
-// THE SHIPPED KERNEL (UOC_HC_VARIANT=2, default): one wave per SIMD (4 waves per block, one block per CU), every wave
-// all ST seed tiles (~330 of its 512 registers), X read exactly once.  Cost model that fits the measurements: a pixel
-// tile costs 32 cycles per MFMA (224) + 2 per VALU (~230) + 8 per v_exp (28) + ~2.7 per MFMA->VALU switch, i.e. the
-// floor of this formulation is ~8 000 cycles per tile against 7 168 of pure MFMA.
-// The 112 KB of LDS serve the epilogue only.  A variant whose waves meet through ONE wave-sized buffer (28 KB, three
-// hand-overs, same summation order) was measured in the three-stream pipeline, on the idea that the block would then
-// share a CU with another stream's convolution block: 122.7-123.1 vs 122.5-123.9 frames/s sustained, the kernel itself
-// +1.5 % — no gain (its 344 registers per lane leave room only for the smallest convolution tiles anyway); not kept.
-template <int ST, int ABL = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void hc_iter_reg1_kernel(
-    const float *__restrict__ X, int n, const float *__restrict__ Z, int m, float kappa, float *__restrict__ partial,
-    int nvb) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.y;
-  X += (size_t)b * n * C;
-  Z += (size_t)b * m * C;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = lane & 15, q = lane >> 4;
-  f32x4 *red = reinterpret_cast<f32x4 *>(smem);  // [4 waves][ST*4][64] f32x4
-  // VIRTUAL blocks: the field is always cut into nvb blocks of 4 waves (nvb depends on n only, hc_virtual_blocks), and the
-  // launch's physical blocks walk them.  Which pixel tiles meet in which partial sum, and the order of every fp32
-  // addition, therefore do not depend on how many fields share the launch (batch), on the CU count or on the grid.
-  for (int vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-    hcr_run<ST, ABL>(X, n, Z, m, 0, kappa, vb * 4 + wave, nvb * 4, red + (size_t)wave * ST * 4 * 64, lane);
+      for (int ct = 0; ct < 4; ++ct) {
+        red_wave[(s * 4 + ct) * 64 + lane] = acc[s][ct];
+        acc[s][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     __syncthreads();
     float *dst = partial + ((size_t)b * nvb + vb) * (ST * 16) * C;
     for (int s = wave; s < ST; s += 4) {
@@ -794,12 +800,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const f32x4 a2 = red[((2 * ST + s) * 4 + ct) * 64 + lane], a3 = red[((3 * ST + s) * 4 + ct) * 64 + lane];
         o[ct] = (a0 + a1) + (a2 + a3);
       }
+      // lane (t,q) reg r holds newZ[seed 16s+4q+r][channel 4t+ct]
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         *reinterpret_cast<float4 *>(dst + (size_t)(16 * s + 4 * q + r) * C + 4 * t) =
             make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
     }
     __syncthreads();  // the reduction buffer is written again by the next virtual block
+    vb += gridDim.x;
+    const int first = vb * 4 + wave;
+    // (only a wave that had no tile in the finished block — tiny fields — does not hold the next block's first tile yet)
+    if (held != first) {
+      held = first;
+      load_tile(held, xa, xb);
+      mask_tile(held, xb);
+    }
   }
 }
 
@@ -1200,10 +1215,14 @@ static int fps_persistent_plan(int batch, int n, int *bpi, int *nslots) {
   int ns = (per_block + FPP_THREADS - 1) / FPP_THREADS;  // pixels per lane
   if (ns > FPP_SLOTS) return 0;  // does not fit on chip: split the batch / use the streaming kernel
   if (ns < 1) ns = 1;
+  // Pack the field onto as few CUs as its pixels need (all FPP_SLOTS pixel slots of every lane: 480x640 on 150 instead of
+  // 200 CUs).  The kernel is bound by the per-step grid exchange, not by its 64 FMAs per pixel, and the CUs it does not
+  // occupy run other streams' kernels meanwhile: 150.0 -> 158.3 frames/s sustained (round 3; UOC_FPS_PACK=0 restores
+  // the spread-out grid, 2 / 3 = at least that many pixels per lane).
   static int pack = -1;
   if (pack < 0) {
-    const char *e = getenv("UOC_FPS_PACK");  // A/B: N = at least N pixels per lane, i.e. the grid on as few CUs as that allows
-    pack = e ? atoi(e) : 0;
+    const char *e = getenv("UOC_FPS_PACK");
+    pack = e ? atoi(e) : FPP_SLOTS;
   }
   if (pack > ns) ns = pack < FPP_SLOTS ? pack : FPP_SLOTS;
   b = (n + FPP_THREADS * ns - 1) / (FPP_THREADS * ns);  // drop blocks that would own no pixel

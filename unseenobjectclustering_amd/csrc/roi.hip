@@ -302,6 +302,20 @@ static int grid_for(int n) {
 
 using namespace uoc;
 
+// ---- label map -> uint8 block row + running maximum (the frame-parallel runner's per-frame output step) ----------
+__global__ __launch_bounds__(256) void labels_to_u8_kernel(const int32_t *__restrict__ lab, long n, uint8_t *__restrict__ out,
+                                                           int32_t *__restrict__ top) {
+  int mx = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int v = lab[i];
+    mx = max(mx, v);
+    out[i] = (uint8_t)v;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(top, mx);
+}
+
 extern "C" {
 
 size_t uoc_roi_workspace_bytes(void) { return carve_roi(nullptr).total; }
@@ -391,6 +405,14 @@ int uoc_roi_paste(const int32_t *d_labels_crop, const uoc_roi_table *d_table, co
   UOC_REQUIRE(K >= 1 && K < NL, "K=%d out of range", K);
   hipLaunchKernelGGL(paste_kernel, dim3(grid_for(H * W)), dim3(256), 0, (hipStream_t)stream, d_labels_crop, d_table,
                      d_map, d_order, K, S, H, W, d_refined);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+int uoc_labels_to_u8(const int32_t *d_labels, long n, uint8_t *d_out, int32_t *d_top, void *stream) {
+  UOC_REQUIRE(d_labels && d_out && d_top && n >= 1, "null pointer / empty map");
+  hipLaunchKernelGGL(labels_to_u8_kernel, dim3(grid_for((int)(n < (1l << 30) ? n : (1l << 30)))), dim3(256), 0,
+                     (hipStream_t)stream, d_labels, n, d_out, d_top);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
 }

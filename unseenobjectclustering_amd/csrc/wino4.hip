@@ -110,9 +110,13 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
   const int wm = wave >> 2, wn = wave & 3;
   const int t = lane & 15, q = lane >> 4;
 
-  const v4i srd_a = make_srd(V, (unsigned)((size_t)NT * Cin * 4));     // range check per plane: voff < plane bytes
-  const v4i srd_w = make_srd(U, (unsigned)((size_t)Cout * Cin * 4));
+  // The descriptors span ALL planes and no lane ever relies on the range check: measured on gfx950, a descriptor of one
+  // plane's size with the plane offset in soffset returned zeros for every plane but the first (the check evidently
+  // covers voffset + soffset here).  Tile rows beyond NT read the last valid row instead: their products land in
+  // accumulator rows the epilogue never stores.
   const unsigned plane_a_bytes = (unsigned)((size_t)NT * Cin * 4), plane_w_bytes = (unsigned)((size_t)Cout * Cin * 4);
+  const v4i srd_a = make_srd(V, (unsigned)planes * plane_a_bytes);
+  const v4i srd_w = make_srd(U, (unsigned)planes * plane_w_bytes);
 
   // per pass: first row of the wave's 8-row group in the stage (compile-time pattern), the lane's row / slot
   int l_r0[NPASS], l_row[NPASS], l_c4[NPASS];
@@ -141,8 +145,8 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
     const int mt_ = iss_rem >> nt_shift, nt_ = iss_rem & (ntiles - 1);                                   \
     _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                                  \
       if (j < NPA) {                                                                                     \
-        const int tau_ = mt_ * BM + l_row[j];                                                            \
-        l_voff[j] = tau_ < NT ? (unsigned)((tau_ * Cin + l_c4[j]) * 4) : kOobVoff;                       \
+        const int tau_ = min(mt_ * BM + l_row[j], NT - 1);                                               \
+        l_voff[j] = (unsigned)((tau_ * Cin + l_c4[j]) * 4);                                              \
       } else {                                                                                           \
         l_voff[j] = (unsigned)(((nt_ * BN + l_row[j]) * Cin + l_c4[j]) * 4);                             \
       }                                                                                                  \
@@ -376,7 +380,8 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
   UOC_REQUIRE(U && ws, "winograd F(4x4): null weight/workspace pointer");
   const Wino4Geom geo = make_geom4(p.B, p.H, p.W, p.dil);
   const int planes = 36 * p.G;
-  UOC_REQUIRE((size_t)planes * geo.NT * (p.Cin > p.Cout ? p.Cin : p.Cout) * 4 < (1ull << 32),
+  UOC_REQUIRE((size_t)planes * geo.NT * (p.Cin > p.Cout ? p.Cin : p.Cout) * 4 < (1ull << 32) &&
+                  (size_t)planes * p.Cout * p.Cin * 4 < (1ull << 32),
               "winograd F(4x4): frequency planes exceed the 4 GB a 32-bit buffer offset addresses (batch too large)");
   float *V = ws, *Mw = ws + (size_t)planes * geo.NT * p.Cin;
   const double Mpix = (double)p.B * p.H * p.W;

@@ -100,9 +100,10 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
     _native.lib().uoc_ms_set_stream_ordering(1 if depth > 1 else 0)   # persistent sampling grids: one at a time per device
     main = torch.cuda.current_stream(device)
     streams = _slot_streams(device, depth)
+    tops = torch.zeros(len(streams), dtype=torch.int32, device=device)   # largest label id per stream (uoc_labels_to_u8)
     for st in streams:
-        st.wait_stream(main)                      # inputs / weights were produced on the caller's stream
-    tops = [torch.zeros((), dtype=torch.int64, device=device) for _ in streams]
+        st.wait_stream(main)                      # inputs / weights (and `tops`) were produced on the caller's stream
+    L = _native.lib()
     nxt = lo
     group = max(1, int(getattr(frame_fn, "frames_per_launch", 1)))
     poll = os.environ.get("UOC_PIPE_POLL", "1") != "0"
@@ -133,9 +134,11 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
                 slots[slot][2] = 2
                 return True
             job.stage3()
-            for i, m in zip(idx, job.final_maps()):
-                tops[slot] = torch.maximum(tops[slot], m.max().to(torch.int64))
-                block[i - lo] = m.to(torch.uint8)
+            for i, m in zip(idx, job.final_maps()):       # int32 [H, W] (contiguous) -> the uint8 row of the block
+                with torch.cuda.device(device):
+                    _native.check(L.uoc_labels_to_u8(_native.ptr(m), m.numel(), _native.ptr(block[i - lo]),
+                                                     _native.ptr(tops[slot:slot + 1]), _native.stream_ptr(device)),
+                                  "uoc_labels_to_u8")
         done_counts[idx[0]] = list(job.K)
         slots[slot] = None
         return True
@@ -165,7 +168,7 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
         frame_fn.roi_counts.extend(done_counts[k])
     for st in streams:
         main.wait_stream(st)
-    return torch.stack(tops).max()
+    return tops.max().to(torch.int64)
 
 
 _streams = {}
