@@ -375,6 +375,14 @@ def main():
 
     from unseenobjectclustering_amd import runner
     sync = (lambda: None) if stub else torch.cuda.synchronize
+    t_setup0 = time.perf_counter()
+    if use_dist and not stub and "UOC_CONV_TUNE_CACHE" not in os.environ:
+        # ONE tile choice per layer shape for the whole job: rank 0 tunes (its setup frames below) and writes the cache,
+        # the other ranks wait at a barrier and load it at their first convolution — every rank then launches identical
+        # kernels (the choices are bit-identical in their results either way; this makes the launch shapes identical too)
+        os.environ["UOC_CONV_TUNE_CACHE"] = os.path.join(tempfile.gettempdir(), f"uoc_conv_tune_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.txt")
+        if rank == 0 and os.path.exists(os.environ["UOC_CONV_TUNE_CACHE"]):
+            os.remove(os.environ["UOC_CONV_TUNE_CACHE"])
 
     lo, hi = runner.shard_range(total, rank, world)
     assert (lo, hi) == _block(total, rank, world)
@@ -393,19 +401,25 @@ def main():
         frame_fn = runner.two_stage_frame_fn(samples, network, network_crop, first_index=lo,     # global index -> resident sample
                                              frames_per_launch=args.frames_per_launch)
 
+    rank_timing = {}
+
     def run(nframes_total, gather):
         maps = runner.run_sharded(nframes_total, frame_fn, h, w, device, rank, world, gather, force_collective=use_dist,
-                                  inflight=args.inflight)
+                                  inflight=args.inflight, timing=rank_timing)
         return maps.cpu()           # label-map block lands on the host inside the timed region
 
     if not stub:
         # setup (never timed, independent of --warmup): the native weight copies, the conv autotuner's choice for
         # every layer shape, and — because the stage-2 batch size (number of ROIs) differs per frame — the first-use
         # work of every batch size (kernel instantiations loading, a tile-height variant's attributes, a tuner lookup)
+        if use_dist and rank != 0:
+            dist.barrier()                            # rank 0 is tuning; its cache file is complete after its barrier
         for g in range(lo, min(hi, lo + 2)):          # one frame at a time first: the tuner's timing launches run alone
             np.random.seed(runner.frame_rng_seed(g))
             frame_fn(g)
         sync()
+        if use_dist and rank == 0:
+            dist.barrier()
         # ... then the same streams x frames-per-launch path the timed region uses, over (up to) 64 frames of the block
         runner.run_sharded(min(hi - lo, 64), frame_fn, h, w, device, 0, 1, False, inflight=args.inflight)
         del frame_fn.roi_counts[:]
@@ -430,7 +444,14 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    print(f"[bench] rank {rank}: timed region {dt:.3f}s", file=sys.stderr, flush=True)
+    rank_timing["setup_s"] = t0 - t_setup0
+    print(f"[bench] rank {rank}: timed region {dt:.3f}s (this rank: setup {rank_timing['setup_s']:.1f}s, compute "
+          f"{rank_timing.get('compute_s', 0.0):.3f}s for {rank_timing.get('frames', 0)} frames, gather "
+          f"{rank_timing.get('gather_s', 0.0):.3f}s)", file=sys.stderr, flush=True)
+    per_rank = [rank_timing]
+    if use_dist:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, {k: round(v, 4) if isinstance(v, float) else v for k, v in rank_timing.items()})
     objects = float(np.mean([int(m.max()) for m in maps[:total]]))
     counts = frame_fn.roi_counts[-(hi - lo):] if frame_fn.roi_counts else []
     rois = float(np.mean(counts)) if counts else 0.0
@@ -595,6 +616,7 @@ def main():
                        "frames_in_flight_per_gpu": args.inflight * args.frames_per_launch,
                        "streams_per_gpu": args.inflight, "frames_per_launch": args.frames_per_launch,
                        "mean_final_objects": round(objects, 2), "mean_rois": round(rois, 2)},
+            "per_rank": [{k: round(v, 4) if isinstance(v, float) else v for k, v in (r or {}).items()} for r in per_rank],
             "pcie_inclusive_frames_per_s": pcie, "latency": latency, "sustained": sustained,
             "roofline": roof, "frame_roofline": frame_roofline(rois, dt / K) if not stub else None,
             "cpu_baseline": cpu, "parity": parity, "kernels": kernels, "conv_by_shape": by_shape if solo and args.profile_steps > 0 else None,

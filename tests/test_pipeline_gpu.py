@@ -66,3 +66,35 @@ def test_launch_sets_with_frames_that_have_no_roi(device):
     for key, b in blocks.items():
         assert torch.equal(ref, b), f"streams={key[0]} frames_per_launch={key[1]} changed a label map"
         assert counts[key] == counts[1, 1]
+
+
+def test_rank_views_concatenate_to_the_single_rank_block(device):
+    """Sharding independence with the REAL frame function (BASELINE configs[4]): the blocks that
+    run_sharded computes as rank r of a world of 2 / 3 / 4 over the same 8 frames, concatenated, equal the block of a
+    single rank — every frame seeds its RNG from its GLOBAL index and no kernel's summation order depends on which
+    frames share a launch set (a rank's launch sets start at its block start, so their composition differs per view:
+    world 3 gives blocks of 3 / 3 / 2 frames)."""
+    cfg.device = device
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    net = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    net_crop = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    F = 8
+    samples = []
+    for g in range(F):
+        s = 10_000 + g
+        fr = synth.palette_frame(s, 480, 640, 5 + s % 3)
+        samples.append(dict(image_color=torch.from_numpy(fr["image_color"]).to(device),
+                            depth=torch.from_numpy(fr["depth"]).to(device)))
+    fn = runner.two_stage_frame_fn(samples, net, net_crop, first_index=0, frames_per_launch=4)
+    whole = runner.run_sharded(F, fn, 480, 640, device, 0, 1, False, inflight=3).cpu()
+    assert whole.shape == (F, 480, 640)
+    for world in (2, 3, 4):
+        parts = []
+        for rank in range(world):
+            lo, hi = runner.shard_range(F, rank, world)
+            # a rank holds only its own frames, like bench.py: samples[lo:hi] with first_index = lo
+            fr_fn = runner.two_stage_frame_fn(samples[lo:hi], net, net_crop, first_index=lo, frames_per_launch=4)
+            parts.append(runner.run_sharded(F, fr_fn, 480, 640, device, rank, world, False, inflight=3).cpu())
+        got = torch.cat(parts)
+        assert got.shape == whole.shape
+        assert torch.equal(got, whole), f"world={world}: the concatenated rank blocks differ from the single-rank block"

@@ -817,9 +817,11 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     return launch_cfg<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
   }
   UOC_REQUIRE(p.Cin % BK == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, BK);
-  UOC_REQUIRE((size_t)p.B * p.H * p.W * p.Cin * 4 + (size_t)(p.pad * p.W + p.pad) * p.Cin * 4 < (1ull << 31),
-              "conv: a group's input exceeds the 2 GB a 32-bit buffer offset addresses");
+  // the LDS-DMA kernel addresses a group's input through a 32-bit buffer offset: beyond 2 GB per group the register-staged
+  // kernel (64-bit addresses) runs instead
+  const bool glds_ok = (size_t)p.B * p.H * p.W * p.Cin * 4 + (size_t)(p.pad * p.W + p.pad) * p.Cin * 4 < (1ull << 31);
   UOC_REQUIRE(p.Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", p.Cout);
+#ifdef UOC_DEV   // timing ablations (WRONG results): compiled only into development builds
   static int variant = -1;
   if (variant < 0) {
     const char *e = getenv("UOC_CONV_VARIANT");  // timing ablations of the 160x128 kernel (dev only)
@@ -835,7 +837,8 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     if (variant == 2) return launch_cfg<160, 128, 2, 4, false, 2>(p, st, KC_CONV_160x128);
     return launch_cfg<160, 128, 2, 4, false, 3>(p, st, KC_CONV_160x128);
   }
-  const Choice ch = choose(p, st, use_glds);
+#endif
+  const Choice ch = glds_ok ? choose(p, st, use_glds) : Choice{pick_cfg(p), 0};
   if (ch.cfg < 0) {
     set_error("conv: no tile configuration for Cout=%d", p.Cout);
     return UOC_EINVAL;

@@ -501,6 +501,7 @@ int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_
     const int v = atoi(e);
     if (v >= 2 && v <= 7) best = v;
   }
+#ifdef UOC_DEV   // timing ablations of the TMT=5 kernel (WRONG results): development builds only
   if (const char *e = getenv("UOC_WINO_VARIANT")) {  // dev: timing ablations of the TMT=5 kernel
     switch (atoi(e)) {
       case 1: return launch_wino_gemm<5, 3, 1>(p, U, Vws, geo, st);
@@ -508,6 +509,7 @@ int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_
       default: break;
     }
   }
+#endif
   switch (best) {
     case 2: return launch_wino_gemm<2, 3>(p, U, Vws, geo, st);
     case 3: return launch_wino_gemm<3, 3>(p, U, Vws, geo, st);

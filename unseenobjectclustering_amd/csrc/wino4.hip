@@ -375,6 +375,20 @@ int launch_wino4_weights(const float *w, float *U, int G, int Cout, int Cin, hip
   return UOC_OK;
 }
 
+// Grid of the two elementwise kernels: every thread owns one (tile, channel quad) item at a time; the grid is capped at
+// the blocks that are resident at once (2 per CU at ~200 VGPRs) so that all blocks walk equally long item ranges and
+// finish together instead of leaving a half-empty last round (UOC_W4_TGRID = blocks per CU, 0 = one block per 256 items).
+static long wino4_elem_blocks(long items) {
+  static int per_cu = -1;
+  if (per_cu < 0) {
+    const char *e = getenv("UOC_W4_TGRID");
+    per_cu = e ? atoi(e) : 0;
+  }
+  long blocks = (items + 255) / 256;
+  const long cap = per_cu > 0 ? (long)per_cu * (device_num_cu() > 0 ? device_num_cu() : 256) : 16384;
+  return blocks < cap ? blocks : cap;
+}
+
 int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_t st) {
   UOC_REQUIRE(wino4_eligible(p), "winograd F(4x4): layer not eligible");
   UOC_REQUIRE(U && ws, "winograd F(4x4): null weight/workspace pointer");
@@ -388,9 +402,7 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
   const ProfTag tag = {{geo.NT, p.Cin, p.Cout, p.dil}};
   {
     ProfScope prof(KC_WINO4_INPUT, st, 0.0, 4.0 * p.G * (Mpix * p.Cin + 36.0 * geo.NT * p.Cin), tag);
-    const long total = (long)p.G * geo.NT * (p.Cin / 4);
-    long blocks = (total + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
+    const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cin / 4));
     hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
     UOC_LAUNCH_CHECK();
   }
@@ -432,9 +444,7 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
   }
   {
     ProfScope prof(KC_WINO4_OUTPUT, st, 0.0, 4.0 * p.G * (36.0 * geo.NT * p.Cout + Mpix * p.Cout * (p.res ? 2 : 1)), tag);
-    const long total = (long)p.G * geo.NT * (p.Cout / 4);
-    long blocks = (total + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
+    const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cout / 4));
     hipLaunchKernelGGL(wino4_output_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G,
                        p.Cout, p.relu);
     UOC_LAUNCH_CHECK();

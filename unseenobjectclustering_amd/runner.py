@@ -33,7 +33,8 @@ def frame_rng_seed(frame_index: int) -> int:
 
 def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height: int, width: int,
                 device: torch.device, rank: int = 0, world: int = 1, gather: bool = True,
-                force_collective: bool = False, inflight: Optional[int] = None) -> Optional[torch.Tensor]:
+                force_collective: bool = False, inflight: Optional[int] = None,
+                timing: Optional[dict] = None) -> Optional[torch.Tensor]:
     """Runs frame_fn(global_index) -> [H,W] integer label map (on `device`) for this rank's block
     and all-gathers the uint8 blocks.  Returns [num_frames, H, W] uint8 on `device` (every rank),
     or only the local block when gather=False / world == 1.
@@ -44,7 +45,12 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
 
     `inflight` (default: $UOC_FRAMES_IN_FLIGHT or 3): when frame_fn offers `make_job` (two_stage_frame_fn does), that
     many frames are kept in flight on this GPU, each on its own stream (_run_block_pipelined); 1 = one frame at a
-    time on the current stream.  The label maps are the same either way."""
+    time on the current stream.  The label maps are the same either way.
+
+    `timing`: if given, receives this rank's 'compute_s' (its frame block, device-synchronised) and 'gather_s' (error-flag
+    all-reduce + all_gather) — the per-rank breakdown bench.py prints for multi-GPU runs."""
+    import time
+    t_start = time.perf_counter()
     per = (num_frames + world - 1) // world
     lo, hi = shard_range(num_frames, rank, world)
     block = torch.zeros((per, height, width), dtype=torch.uint8, device=device)
@@ -70,8 +76,14 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
         if not collective:
             raise
         error = e
+    if timing is not None:
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        timing["compute_s"] = time.perf_counter() - t_start
+        timing["frames"] = hi - lo
     if not collective:
         return block[:hi - lo]
+    t_gather = time.perf_counter()
     flag = torch.tensor([1 if error is not None else 0], dtype=torch.int32, device=device)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     if int(flag.item()) != 0:
@@ -80,6 +92,10 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
         raise RuntimeError("another rank failed in its frame block; aborting before the all_gather")
     full = torch.empty((world * per, height, width), dtype=torch.uint8, device=device)
     dist.all_gather_into_tensor(full, block)
+    if timing is not None:
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        timing["gather_s"] = time.perf_counter() - t_gather
     return full[:num_frames]
 
 
