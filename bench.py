@@ -551,6 +551,13 @@ def main():
                                  "executed_tflops": round(factor * sh["flops"] / sh["total_ms"] / 1e9, 1),
                                  "algorithmic_gbs": round(sh["bytes"] / sh["total_ms"] / 1e6, 1)})
         by_shape.sort(key=lambda d: -d["avg_us"] * d["launches"])
+        clustering_by_shape = []      # hc_iter: tag = [pixels, fields, virtual blocks, physical blocks per field]; fps: [pixels, fields, blocks per field, pixels per lane]
+        for r in rep:
+            if r["kernel"] in ("hc_iter", "fps_step"):
+                for sh in r.get("shapes", []):
+                    clustering_by_shape.append({"kernel": r["kernel"], "tag": sh["tag"], "launches": sh["launches"],
+                                                "avg_us": round(1e3 * sh["total_ms"] / sh["launches"], 1),
+                                                "tflops": round(sh["flops"] / sh["total_ms"] / 1e9, 1)})
         dom = max(rep, key=lambda r: r["total_ms"])
         sec = dom["total_ms"] / 1e3
         traffic = None
@@ -620,6 +627,7 @@ def main():
             "pcie_inclusive_frames_per_s": pcie, "latency": latency, "sustained": sustained,
             "roofline": roof, "frame_roofline": frame_roofline(rois, dt / K) if not stub else None,
             "cpu_baseline": cpu, "parity": parity, "kernels": kernels, "conv_by_shape": by_shape if solo and args.profile_steps > 0 else None,
+            "clustering_by_shape": clustering_by_shape if solo and args.profile_steps > 0 else None,
         }
     else:
         line = None

@@ -1,0 +1,9 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+export PYTHONUNBUFFERED=1
+for t in 16 32 75 98; do UOC_HC_VB_TILES=$t timeout 200 python bench.py --steps 24 --cpu-frames 0 --sustained-seconds 5 --skip-pcie > gpurun_out/r3h_bench_t$t.json 2> gpurun_out/r3h_bench_t$t.err; python - <<PY
+import json
+d=json.load(open("gpurun_out/r3h_bench_t$t.json")); print("tiles$t", d["value"], d["sustained"]["frames_per_s"], d["latency"]["frames_per_s"])
+for x in d["clustering_by_shape"]: print("   ", x)
+PY
+done

@@ -56,6 +56,8 @@ for name, B, H, W, C, dil in shapes:
                        ("F4 persistent 96x128", {"UOC_CONV_WINOGRAD": "4", "UOC_WINO4_GEMM": "2", "UOC_WINO4_TILE": "96x128"}),
                        ("F4 persistent 192x64", {"UOC_CONV_WINOGRAD": "4", "UOC_WINO4_GEMM": "2", "UOC_WINO4_TILE": "192x64"}),
                        ("direct", {})):
+        if os.environ.get("WINO4_BENCH_ONLY") and os.environ["WINO4_BENCH_ONLY"] not in label:
+            continue
         try:
             rep = measure(B, H, W, C, dil, env)
         except Exception as e:  # noqa: BLE001

@@ -18,6 +18,7 @@ static float frand() {  // xorshift, uniform in [-1, 1)
   return (float)((double)(s_rng >> 11) / 9007199254740992.0 * 2.0 - 1.0);
 }
 
+template <int VEC>
 static int run_case(int G, int B, int H, int W, int Cin, int Cout, int d, bool use_res, int relu) {
   const Wino4Geom geo = make_geom4(B, H, W, d);
   std::vector<float> in((size_t)G * B * H * W * Cin), w((size_t)G * 9 * Cout * Cin), bias((size_t)G * Cout),
@@ -32,7 +33,7 @@ static int run_case(int G, int B, int H, int W, int Cin, int Cout, int d, bool u
       for (int ci = 0; ci < Cin; ++ci) wino4_weight_body(w.data(), U.data(), G, Cout, Cin, g, co, ci);
   for (int g = 0; g < G; ++g)
     for (int tau = 0; tau < geo.NT; ++tau)
-      for (int c4 = 0; c4 < Cin / 4; ++c4) wino4_input_body(in.data(), V.data(), geo, Cin, g, tau, c4);
+      for (int cv = 0; cv < Cin / VEC; ++cv) wino4_input_body<VEC>(in.data(), V.data(), geo, Cin, g, tau, cv);
   // the batched GEMM: M[g*36+xi][tile][cout] = sum_cin V[g*36+xi][tile][cin] * U[g*36+xi][cout][cin]  (fp32 accumulate)
   for (int gx = 0; gx < G * 36; ++gx)
     for (int tau = 0; tau < geo.NT; ++tau)
@@ -44,8 +45,8 @@ static int run_case(int G, int B, int H, int W, int Cin, int Cout, int d, bool u
       }
   for (int g = 0; g < G; ++g)
     for (int tau = 0; tau < geo.NT; ++tau)
-      for (int c4 = 0; c4 < Cout / 4; ++c4)
-        wino4_output_body(M.data(), bias.data(), use_res ? res.data() : nullptr, out.data(), geo, Cout, relu, g, tau, c4);
+      for (int cv = 0; cv < Cout / VEC; ++cv)
+        wino4_output_body<VEC>(M.data(), bias.data(), use_res ? res.data() : nullptr, out.data(), geo, Cout, relu, g, tau, cv);
   double worst = 0.0, scale = 1.0;
   for (int g = 0; g < G; ++g)
     for (int b = 0; b < B; ++b)
@@ -69,18 +70,18 @@ static int run_case(int G, int B, int H, int W, int Cin, int Cout, int d, bool u
             if (fabs(acc) > scale) scale = fabs(acc);
           }
   const bool ok = worst < 2e-5 * scale;
-  printf("G%d B%d %dx%d %d->%d d%d res%d relu%d: tiles %d, max abs err %.3e (scale %.2f) %s\n", G, B, H, W, Cin, Cout, d,
+  printf("vec%d G%d B%d %dx%d %d->%d d%d res%d relu%d: tiles %d, max abs err %.3e (scale %.2f) %s\n", VEC, G, B, H, W, Cin, Cout, d,
          (int)use_res, relu, geo.NT, worst, scale, ok ? "ok" : "FAIL");
   return ok ? 0 : 1;
 }
 
 int main() {
   int bad = 0;
-  bad += run_case(1, 1, 8, 8, 8, 8, 1, false, 0);
-  bad += run_case(2, 1, 15, 20, 8, 12, 1, true, 1);    // partial tiles
-  bad += run_case(1, 2, 14, 14, 8, 8, 2, true, 1);     // 7x7 phase images
-  bad += run_case(1, 1, 15, 20, 16, 8, 4, false, 1);   // phases of 4x5 / 3x5 pixels
-  bad += run_case(2, 2, 13, 9, 4, 8, 2, false, 0);     // ragged
-  bad += run_case(1, 1, 3, 5, 4, 4, 4, true, 0);       // image smaller than the dilation
+  bad += run_case<4>(1, 1, 8, 8, 8, 8, 1, false, 0);
+  bad += run_case<4>(2, 1, 15, 20, 8, 12, 1, true, 1);    // partial tiles
+  bad += run_case<2>(1, 2, 14, 14, 8, 8, 2, true, 1);     // 7x7 phase images
+  bad += run_case<1>(1, 1, 15, 20, 16, 8, 4, false, 1);   // phases of 4x5 / 3x5 pixels
+  bad += run_case<2>(2, 2, 13, 9, 4, 8, 2, false, 0);     // ragged
+  bad += run_case<1>(1, 1, 3, 5, 4, 4, 4, true, 0);       // image smaller than the dilation
   return bad ? 1 : 0;
 }

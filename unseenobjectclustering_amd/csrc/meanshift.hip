@@ -1112,7 +1112,12 @@ static int hc_variant() {
 // map could then depend on its launch-set mates.)
 static int hc_virtual_blocks(int n) {
   const int ntile = (n + 15) / 16;
-  int nvb = (ntile + 63) / 64;
+  static int tiles_per_wave = 0;
+  if (!tiles_per_wave) {
+    const char *e = getenv("UOC_HC_VB_TILES");   // dev (changes the summation order, i.e. the last bits of the seeds): pixel tiles per wave and virtual block
+    tiles_per_wave = e && atoi(e) > 0 ? atoi(e) : 16;
+  }
+  int nvb = (ntile + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
   if (nvb > 256) nvb = 256;
   if (nvb < 1) nvb = 1;
   return nvb;
@@ -1133,7 +1138,7 @@ static int hc_physical_blocks(int batch, int nvb, int per_cu) {
   for (int p = 1; p <= nvb; ++p) {
     const long rounds = ((long)p * batch + slots - 1) / slots;
     const long cost = rounds * ((nvb + p - 1) / p);
-    if (best_cost < 0 || cost <= best_cost) {   // ties: more (smaller) blocks
+    if (best_cost < 0 || cost < best_cost) {   // ties: fewer blocks, each walking more virtual blocks (one prologue, pipelined)
       best_cost = cost;
       best = p;
     }
@@ -1306,7 +1311,8 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
       hipEvent_t ev = g_fps_stream_ordering.load() ? chain.event() : nullptr;
       if (ev) UOC_HIP_CHECK(hipStreamWaitEvent(st, ev, 0));
       {
-        ProfScope prof(KC_FPS_STEP, st, 2.0 * sub * (double)n * C * (m - 1), 4.0 * sub * (double)n * C);
+        ProfScope prof(KC_FPS_STEP, st, 2.0 * sub * (double)n * C * (m - 1), 4.0 * sub * (double)n * C,
+                       ProfTag{{n, sub, bpi, nslots}});
         if (fps_cooperative())
           e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&fps_persistent_kernel), dim3(sub * bpi),
                                          dim3(FPP_THREADS), args, (unsigned)lds, st);
@@ -1381,7 +1387,7 @@ static void launch_hc(const float *X, int batch, int n, float *Z, int m, float k
     {
       // NH = 2 recomputes S for each half of the accumulators: (2 + 1) / 2 of the algorithmic flops per half
       ProfScope prof(KC_HC_ITER, st, 4.0 * batch * m * (double)n * C * NH,
-                     4.0 * batch * ((double)n * C * NH + 2.0 * m * C * NH));
+                     4.0 * batch * ((double)n * C * NH + 2.0 * m * C * NH), ProfTag{{n, batch, nvb, phys}});
       if constexpr (NH == 1) {
         if (reg) {
           const dim3 g(phys, batch), bdim(256);

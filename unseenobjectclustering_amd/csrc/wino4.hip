@@ -39,28 +39,30 @@ __global__ __launch_bounds__(256) void wino4_weight_kernel(const float *__restri
   }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restrict__ in, float *__restrict__ V,
                                                           Wino4Geom geo, int G, int C) {
-  const int C4 = C >> 2;
-  const long total = (long)G * geo.NT * C4;
+  const int CV = C / VEC;
+  const long total = (long)G * geo.NT * CV;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % C4);
-    const int tau = (int)((idx / C4) % geo.NT);
-    const int g = (int)(idx / ((long)C4 * geo.NT));
-    wino4_input_body(in, V, geo, C, g, tau, c4);
+    const int cv = (int)(idx % CV);
+    const int tau = (int)((idx / CV) % geo.NT);
+    const int g = (int)(idx / ((long)CV * geo.NT));
+    wino4_input_body<VEC>(in, V, geo, C, g, tau, cv);
   }
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restrict__ M, const float *__restrict__ bias,
                                                            const float *__restrict__ res, float *__restrict__ out,
                                                            Wino4Geom geo, int G, int Cout, int relu) {
-  const int C4 = Cout >> 2;
-  const long total = (long)G * geo.NT * C4;
+  const int CV = Cout / VEC;
+  const long total = (long)G * geo.NT * CV;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int c4 = (int)(idx % C4);
-    const int tau = (int)((idx / C4) % geo.NT);
-    const int g = (int)(idx / ((long)C4 * geo.NT));
-    wino4_output_body(M, bias, res, out, geo, Cout, relu, g, tau, c4);
+    const int cv = (int)(idx % CV);
+    const int tau = (int)((idx / CV) % geo.NT);
+    const int g = (int)(idx / ((long)CV * geo.NT));
+    wino4_output_body<VEC>(M, bias, res, out, geo, Cout, relu, g, tau, cv);
   }
 }
 
@@ -400,10 +402,23 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
   float *V = ws, *Mw = ws + (size_t)planes * geo.NT * p.Cin;
   const double Mpix = (double)p.B * p.H * p.W;
   const ProfTag tag = {{geo.NT, p.Cin, p.Cout, p.dil}};
+  // channels per thread of the two elementwise kernels: 4 (float4) moves the most bytes per instruction; 1 or 2 need a
+  // quarter / half of the registers (UOC_W4_VEC, A/B)
+  static int vec = 0;
+  if (!vec) {
+    const char *e = getenv("UOC_W4_VEC");
+    vec = e ? atoi(e) : 4;
+    if (vec != 1 && vec != 2) vec = 4;
+  }
   {
     ProfScope prof(KC_WINO4_INPUT, st, 0.0, 4.0 * p.G * (Mpix * p.Cin + 36.0 * geo.NT * p.Cin), tag);
-    const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cin / 4));
-    hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
+    const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cin / vec));
+    if (vec == 1)
+      hipLaunchKernelGGL(wino4_input_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
+    else if (vec == 2)
+      hipLaunchKernelGGL(wino4_input_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
+    else
+      hipLaunchKernelGGL(wino4_input_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
     UOC_LAUNCH_CHECK();
   }
   int gemm_mode = 2;   // 2 = the persistent plane-GEMM kernel; 1 = one direct 1x1 "convolution" over 36*G groups (A/B, dev)
@@ -444,9 +459,13 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
   }
   {
     ProfScope prof(KC_WINO4_OUTPUT, st, 0.0, 4.0 * p.G * (36.0 * geo.NT * p.Cout + Mpix * p.Cout * (p.res ? 2 : 1)), tag);
-    const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cout / 4));
-    hipLaunchKernelGGL(wino4_output_kernel, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G,
-                       p.Cout, p.relu);
+    const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cout / vec));
+    if (vec == 1)
+      hipLaunchKernelGGL(wino4_output_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
+    else if (vec == 2)
+      hipLaunchKernelGGL(wino4_output_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
+    else
+      hipLaunchKernelGGL(wino4_output_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
     UOC_LAUNCH_CHECK();
   }
   return UOC_OK;

@@ -52,12 +52,29 @@ __host__ __device__ inline float w4_fma(float c, float a, float b) { return fmaf
 __host__ __device__ inline float w4_add(float a, float b) { return a + b; }
 __host__ __device__ inline float w4_sub(float a, float b) { return a - b; }
 __host__ __device__ inline float w4_neg(float a) { return -a; }
+__host__ __device__ inline float2 w4_fma(float c, float2 a, float2 b) { return make_float2(fmaf(c, a.x, b.x), fmaf(c, a.y, b.y)); }
+__host__ __device__ inline float2 w4_add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__host__ __device__ inline float2 w4_sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__host__ __device__ inline float2 w4_neg(float2 a) { return make_float2(-a.x, -a.y); }
 __host__ __device__ inline float4 w4_fma(float c, float4 a, float4 b) {
   return make_float4(fmaf(c, a.x, b.x), fmaf(c, a.y, b.y), fmaf(c, a.z, b.z), fmaf(c, a.w, b.w));
 }
 __host__ __device__ inline float4 w4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __host__ __device__ inline float4 w4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 __host__ __device__ inline float4 w4_neg(float4 a) { return make_float4(-a.x, -a.y, -a.z, -a.w); }
+
+// channel vectors of 1, 2 or 4 floats: the elementwise kernels are instantiated for all three widths (fewer channels per
+// thread = fewer registers per thread = waves that fit beside another stream's matrix kernel on the same SIMD)
+template <int VEC> struct W4Vec;
+template <> struct W4Vec<1> { typedef float type; };
+template <> struct W4Vec<2> { typedef float2 type; };
+template <> struct W4Vec<4> { typedef float4 type; };
+__host__ __device__ inline void w4_zero(float &v) { v = 0.f; }
+__host__ __device__ inline void w4_zero(float2 &v) { v = make_float2(0.f, 0.f); }
+__host__ __device__ inline void w4_zero(float4 &v) { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+__host__ __device__ inline float w4_relu(float v) { return fmaxf(v, 0.f); }
+__host__ __device__ inline float2 w4_relu(float2 v) { return make_float2(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)); }
+__host__ __device__ inline float4 w4_relu(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
 
 // o = B^T i,   B^T = [[1, 1.5, -2, -1.5, 1, 0], [0, -1, -2.5, -0.5, 1, 0], [0, 1, 0.5, -2.5, 1, 0],
 //                     [0, -0.5, -1, 0.5, 1, 0], [0, 2, -1, -2, 1, 0],      [0, 1, 1.5, -2, -1.5, 1]]
@@ -113,48 +130,55 @@ __host__ __device__ inline void wino4_weight_body(const float *w, float *U, int 
   (void)G;
 }
 
-// V[(g*36 + xi)][tile][cin] = (B^T d B)[xi] for channels 4*c4 .. 4*c4+3 of tile tau; in: [g][B][H][W][C]
-__host__ __device__ inline void wino4_input_body(const float *in, float *V, const Wino4Geom &geo, int C, int g, int tau, int c4) {
+// V[(g*36 + xi)][tile][cin] = (B^T d B)[xi] for channels VEC*cv .. VEC*cv+VEC-1 of tile tau; in: [g][B][H][W][C]
+template <int VEC>
+__host__ __device__ inline void wino4_input_body(const float *in, float *V, const Wino4Geom &geo, int C, int g, int tau, int cv) {
+  typedef typename W4Vec<VEC>::type T;
   int b, oy, ox;
   wino4_decode(tau, geo, b, oy, ox);
-  const float *src = in + (((size_t)g * geo.B + b) * geo.H * geo.W) * C + 4 * c4;
-  float4 t[6][6];
+  const float *src = in + (((size_t)g * geo.B + b) * geo.H * geo.W) * C + VEC * cv;
+  T t[6][6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const int x = ox + (j - 1) * geo.d;
-    float4 col[6], o[6];
+    T col[6], o[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int y = oy + (i - 1) * geo.d;
       const bool ok = (unsigned)y < (unsigned)geo.H && (unsigned)x < (unsigned)geo.W;
-      col[i] = ok ? *reinterpret_cast<const float4 *>(src + ((size_t)y * geo.W + x) * C) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok)
+        col[i] = *reinterpret_cast<const T *>(src + ((size_t)y * geo.W + x) * C);
+      else
+        w4_zero(col[i]);
     }
     wino4_bt(col, o);
 #pragma unroll
     for (int i = 0; i < 6; ++i) t[i][j] = o[i];
   }
   const size_t plane = (size_t)geo.NT * C;
-  float *dst = V + (size_t)g * 36 * plane + (size_t)tau * C + 4 * c4;
+  float *dst = V + (size_t)g * 36 * plane + (size_t)tau * C + VEC * cv;
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
-    float4 o[6];
+    T o[6];
     wino4_bt(t[i], o);
 #pragma unroll
-    for (int j = 0; j < 6; ++j) *reinterpret_cast<float4 *>(dst + (size_t)(6 * i + j) * plane) = o[j];
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<T *>(dst + (size_t)(6 * i + j) * plane) = o[j];
   }
 }
 
-// out[g][b][y][x][cout] = relu?(A^T M A + bias (+ res)) for channels 4*c4 .. of tile tau; M: [(g*36 + xi)][tile][cout]
+// out[g][b][y][x][cout] = relu?(A^T M A + bias (+ res)) for channels VEC*cv .. of tile tau; M: [(g*36 + xi)][tile][cout]
+template <int VEC>
 __host__ __device__ inline void wino4_output_body(const float *M, const float *bias, const float *res, float *out,
-                                                  const Wino4Geom &geo, int Cout, int relu, int g, int tau, int c4) {
+                                                  const Wino4Geom &geo, int Cout, int relu, int g, int tau, int cv) {
+  typedef typename W4Vec<VEC>::type T;
   const size_t plane = (size_t)geo.NT * Cout;
-  const float *src = M + (size_t)g * 36 * plane + (size_t)tau * Cout + 4 * c4;
-  float4 s[4][6];
+  const float *src = M + (size_t)g * 36 * plane + (size_t)tau * Cout + VEC * cv;
+  T s[4][6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
-    float4 col[6], o[4];
+    T col[6], o[4];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const float4 *>(src + (size_t)(6 * i + j) * plane);
+    for (int i = 0; i < 6; ++i) col[i] = *reinterpret_cast<const T *>(src + (size_t)(6 * i + j) * plane);
     wino4_at(col, o);
 #pragma unroll
     for (int a = 0; a < 4; ++a) s[a][j] = o[a];
@@ -162,10 +186,10 @@ __host__ __device__ inline void wino4_output_body(const float *M, const float *b
   int b, oy, ox;
   wino4_decode(tau, geo, b, oy, ox);
   const size_t gsz = (size_t)geo.B * geo.H * geo.W * Cout;
-  const float4 bv = *reinterpret_cast<const float4 *>(bias + (size_t)g * Cout + 4 * c4);
+  const T bv = *reinterpret_cast<const T *>(bias + (size_t)g * Cout + VEC * cv);
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
-    float4 yv[4];
+    T yv[4];
     wino4_at(s[a], yv);
     const int y = oy + a * geo.d;
     if (y >= geo.H) continue;
@@ -173,11 +197,11 @@ __host__ __device__ inline void wino4_output_body(const float *M, const float *b
     for (int e = 0; e < 4; ++e) {
       const int x = ox + e * geo.d;
       if (x >= geo.W) continue;
-      const size_t o = (size_t)g * gsz + (((size_t)b * geo.H + y) * geo.W + x) * Cout + 4 * c4;
-      float4 v = w4_add(yv[e], bv);
-      if (res) v = w4_add(v, *reinterpret_cast<const float4 *>(res + o));
-      if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-      *reinterpret_cast<float4 *>(out + o) = v;
+      const size_t o = (size_t)g * gsz + (((size_t)b * geo.H + y) * geo.W + x) * Cout + VEC * cv;
+      T v = w4_add(yv[e], bv);
+      if (res) v = w4_add(v, *reinterpret_cast<const T *>(res + o));
+      if (relu) v = w4_relu(v);
+      *reinterpret_cast<T *>(out + o) = v;
     }
   }
 }
