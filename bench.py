@@ -319,7 +319,7 @@ def stub_frame_fn(h, w):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20, help="frames per GPU (weak scaling)")
+    ap.add_argument("--steps", type=int, default=64, help="frames per GPU (weak scaling)")
     ap.add_argument("--frames", type=int, default=0,
                     help="strong scaling: this many frames in total, sharded in contiguous blocks over the GPUs")
     ap.add_argument("--warmup", type=int, default=3)
@@ -331,6 +331,7 @@ def main():
     ap.add_argument("--frames-per-launch", type=int, default=int(os.environ.get("UOC_FRAMES_PER_LAUNCH", "4")),
                     help="frames batched into one set of launches per stage (fcn.test_dataset.FrameGroupJob)")
     ap.add_argument("--skip-pcie", action="store_true", help="skip the PCIe-inclusive leg (profiling runs)")
+    ap.add_argument("--skip-latency", action="store_true", help="skip the one-frame-at-a-time latency leg (profiling runs)")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
@@ -482,7 +483,7 @@ def main():
         pcie = round(total / (time.perf_counter() - t1), 3)
 
     latency = None
-    if solo:
+    if solo and not args.skip_latency:
         # BASELINE configs[3] read literally ("batch=1"): ONE frame at a time on one stream, host waiting for each result
         nlat = min(hi - lo, 12)
         for g in range(lo, lo + min(nlat, 2)):
@@ -550,6 +551,8 @@ def main():
                                  "algorithmic_tflops": round(sh["flops"] / sh["total_ms"] / 1e9, 1),
                                  "executed_tflops": round(factor * sh["flops"] / sh["total_ms"] / 1e9, 1),
                                  "algorithmic_gbs": round(sh["bytes"] / sh["total_ms"] / 1e6, 1)})
+                if r["kernel"] == "wino4_gemm":   # every MFMA the kernel issues, partial 4x4 tiles included: 72 planes (two branches) of [rows x Cin] x [Cin x Cout]
+                    by_shape[-1]["matrix_pipe_tflops"] = round(72 * 2.0 * sh["tag"][0] * sh["tag"][1] * sh["tag"][2] * sh["launches"] / sh["total_ms"] / 1e9, 1)
         by_shape.sort(key=lambda d: -d["avg_us"] * d["launches"])
         clustering_by_shape = []      # hc_iter: tag = [pixels, fields, virtual blocks, physical blocks per field]; fps: [pixels, fields, blocks per field, pixels per lane]
         for r in rep:
@@ -578,8 +581,13 @@ def main():
                 roof["algorithmic_frac"] = roof["frac"]
                 roof["achieved"] = round(ach * 0.25, 2)
                 roof["frac"] = round(ach * 0.25 / PEAK_FP32_TFLOPS, 4)
+                pipe = sum(72 * 2.0 * d["rows"] * d["cin"] * d["cout"] * d["launches"] for d in roof["by_shape"]) / sec / 1e12
+                roof["matrix_pipe_tflops"] = round(pipe, 2)
+                roof["matrix_pipe_frac"] = round(pipe / PEAK_FP32_TFLOPS, 4)
                 roof["note"] = ("Winograd F(4x4,3x3): achieved = MFMA flops executed for real outputs (36/144 of the direct "
-                                "conv's); algorithmic_* = SURVEY 8(d) direct-conv flops over the same time")
+                                "conv's); matrix_pipe_* = every MFMA issued, the padded rows of partial 4x4 tiles included (7 % "
+                                "at 60x80, 31 % on the 7x7 / 14x14 phase images of the 28x28 crop features); algorithmic_* = "
+                                "SURVEY 8(d) direct-conv flops over the same time")
             if dom["kernel"] == "wino_gemm":
                 # the prof class counts the ALGORITHMIC (direct 3x3) flops; Winograd F(2x2,3x3) issues 16/36 of them
                 # to the matrix pipe.  `achieved` / `frac` are the flops the pipe really executes (a fraction of a

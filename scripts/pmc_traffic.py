@@ -37,7 +37,8 @@ def klass(name):
         if m.group(5) == "true":
             return "conv_stem"
         return "conv_glds_%sx%s" % ("160" if m.group(3) == "2" else "80", m.group(2))
-    for k, v in (("wino_gemm", "wino_gemm"), ("wino_input", "wino_input"), ("hc_iter", "hc_iter"),
+    for k, v in (("wino4_gemm", "wino4_gemm"), ("wino4_input", "wino4_input"), ("wino4_output", "wino4_output"),
+                 ("wino_gemm", "wino_gemm"), ("wino_input", "wino_input"), ("hc_iter", "hc_iter"),
                  ("hc_finalize", "hc_finalize"), ("fps_", "fps_step"), ("assign_kernel", "assign"), ("head_", "head")):
         if k in name:
             return v
