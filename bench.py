@@ -409,18 +409,22 @@ def main():
                                   inflight=args.inflight, timing=rank_timing)
         return maps.cpu()           # label-map block lands on the host inside the timed region
 
+    # setup (never timed, independent of --warmup): the native weight copies, the conv autotuner's choice for every layer
+    # shape, and — because the stage-2 batch size (number of ROIs) differs per frame — the first-use work of every batch
+    # size (kernel instantiations loading, a tile-height variant's attributes, a tuner lookup).
+    # Rank 0 runs its first frames (= the tuning launches) before the others start theirs: they load its choices from the
+    # cache file (UOC_CONV_TUNE_CACHE above).  The two barriers below pair up on every rank (also in --stub runs, so that
+    # the CPU launcher test covers the ordering).
+    if use_dist and rank != 0:
+        dist.barrier()                            # rank 0 is tuning; its cache file is complete after its barrier
     if not stub:
-        # setup (never timed, independent of --warmup): the native weight copies, the conv autotuner's choice for
-        # every layer shape, and — because the stage-2 batch size (number of ROIs) differs per frame — the first-use
-        # work of every batch size (kernel instantiations loading, a tile-height variant's attributes, a tuner lookup)
-        if use_dist and rank != 0:
-            dist.barrier()                            # rank 0 is tuning; its cache file is complete after its barrier
         for g in range(lo, min(hi, lo + 2)):          # one frame at a time first: the tuner's timing launches run alone
             np.random.seed(runner.frame_rng_seed(g))
             frame_fn(g)
         sync()
-        if use_dist and rank == 0:
-            dist.barrier()
+    if use_dist and rank == 0:
+        dist.barrier()
+    if not stub:
         # ... then the same streams x frames-per-launch path the timed region uses, over (up to) 64 frames of the block
         runner.run_sharded(min(hi - lo, 64), frame_fn, h, w, device, 0, 1, False, inflight=args.inflight)
         del frame_fn.roi_counts[:]

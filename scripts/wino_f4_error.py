@@ -53,8 +53,17 @@ def rebalance(AT, G, BT, scale):
     return AT, G / s[:, None], BT * s[:, None]
 
 
+def split3(x):
+    """x = x1 + x2 + x3 (+ ~2^-24 |x|) with bf16 terms: what a split-precision GEMM on the bf16 matrix pipe would feed."""
+    x1 = x.to(torch.bfloat16).to(torch.float32)
+    r = x - x1
+    x2 = r.to(torch.bfloat16).to(torch.float32)
+    x3 = (r - x2).to(torch.bfloat16).to(torch.float32)
+    return x1, x2, x3
+
+
 class Wino:
-    def __init__(self, m, points, dtype=torch.float32, scale=None):
+    def __init__(self, m, points, dtype=torch.float32, scale=None, bf16x3=0):
         AT, G, BT = cook_toom(points, m)
         if scale is not None:
             AT, G, BT = rebalance(AT, G, BT, scale)
@@ -63,6 +72,7 @@ class Wino:
         self.AT = torch.tensor(AT, dtype=dtype)
         self.BT = torch.tensor(BT, dtype=dtype)
         self.dtype = dtype
+        self.bf16x3 = bf16x3     # 0 = fp32 GEMM; 6 / 3 = products kept of the 3 x 3 bf16 term pairs (hh hm mh hl lh mm / hh hm mh)
 
     def conv(self, x, w, dil):
         """x [B,C,H,W] fp32, w [Co,C,3,3] fp32 -> [B,Co,H,W] (stride 1, padding = dilation)."""
@@ -79,7 +89,12 @@ class Wino:
                 xpad = F.pad(xp, (1, tw * m - wd + 1, 1, th * m - h + 1))
                 patches = xpad.unfold(2, n, m).unfold(3, n, m)          # [B,C,th,tw,n,n]
                 V = torch.einsum("ia,bcyxae,je->ijbyxc", self.BT, patches.to(self.dtype), self.BT)
-                M = torch.einsum("ijbyxc,ijoc->ijbyxo", V, U)
+                if self.bf16x3:
+                    v, u = split3(V), split3(U)
+                    pairs = [(0, 0), (0, 1), (1, 0), (0, 2), (2, 0), (1, 1)][:self.bf16x3]
+                    M = sum(torch.einsum("ijbyxc,ijoc->ijbyxo", v[a], u[b]) for a, b in reversed(pairs))   # small terms first
+                else:
+                    M = torch.einsum("ijbyxc,ijoc->ijbyxo", V, U)
                 Y = torch.einsum("ai,ijbyxo,ej->boyaxe", self.AT, M, self.AT)   # [B,Co,th,m,tw,m]
                 Y = Y.reshape(B, -1, th * m, tw * m)[:, :, :h, :wd]
                 out[:, :, py::dil, px::dil] = Y
@@ -149,12 +164,16 @@ def main():
         "F4 (0,1,-1,1/2,-1/2)": Wino(4, [0, 1, -1, Fraction(1, 2), Fraction(-1, 2)]),
         "F4 (0,1,-1,1/2,-2)": Wino(4, [0, 1, -1, Fraction(1, 2), -2]),
         "F4 (0,1,-1,2,-1/2)": Wino(4, [0, 1, -1, 2, Fraction(-1, 2)]),
+        "F4 (0,1,-1,2,-1/2) bf16x3, 6 products": Wino(4, [0, 1, -1, 2, Fraction(-1, 2)], bf16x3=6),
+        "F4 (0,1,-1,2,-1/2) bf16x3, 3 products": Wino(4, [0, 1, -1, 2, Fraction(-1, 2)], bf16x3=3),
     }
+    if os.environ.get("WINO_STUDY_ONLY"):
+        cands = {k: v for k, v in cands.items() if os.environ["WINO_STUDY_ONLY"] in k}
     for name, wz in cands.items():
         e = embed(sd, img, xyz, wz.conv, torch.float32)
         d64 = (e.double() - ref64).abs()
         d32 = (e - direct32).abs()
-        print(f"{name:28s} vs fp64: max {float(d64.max()):.3e} mean {float(d64.mean()):.3e}   vs direct fp32: max {float(d32.max()):.3e}")
+        print(f"{name:40s} vs fp64: max {float(d64.max()):.3e} mean {float(d64.mean()):.3e}   vs direct fp32: max {float(d32.max()):.3e}")
 
 
 if __name__ == "__main__":

@@ -136,6 +136,30 @@ def test_batched_equals_individual(device):
         assert torch.equal(l1[0], lb[k]) and torch.equal(i1[0], ib[k])
 
 
+@pytest.mark.parametrize("shape", [(224, 224), (480, 640), (37, 53)])
+def test_converged_seeds_do_not_depend_on_the_batch(device, shape):
+    """The fp32 summation order of a hill-climbing iteration must depend on the field only (virtual blocks,
+    csrc/meanshift.hip): the converged seed positions Z of a field are BIT-identical whether it is clustered alone, with
+    three other fields or among 29 — for every batch the physical grid differs (blocks per field, virtual blocks per
+    block, rounds of CUs).  (Round 2 derived the block count from the batch; the label maps agreed only because no
+    pixel of the test fields sat on a near-tie.)"""
+    H, W = shape
+    X, _ = synth.embedding_field(31, H, W, 64, 6, 0.05)
+    x0 = torch.from_numpy(X).to(device)
+    first = 4321 % (H * W)
+    _, _, z1, s1 = MS.cluster_batch(x0[None], [first], KAPPA, 100, 10, EPSILON, return_parts=True)
+    for batch in ((4, 30) if H * W <= 224 * 224 else (2, 4)):
+        others = [torch.from_numpy(synth.embedding_field(40 + k, H, W, 64, 3 + k % 4, 0.05)[0]) for k in range(min(batch - 1, 3))]
+        fields = [x0] + [others[k % len(others)].to(device) for k in range(batch - 1)]
+        pos = batch // 2                                   # the field under test somewhere in the middle
+        fields[0], fields[pos] = fields[pos], fields[0]
+        firsts = [(first + 17 * k) % (H * W) for k in range(batch)]
+        firsts[pos] = first
+        _, _, zb, sb = MS.cluster_batch(torch.stack(fields), firsts, KAPPA, 100, 10, EPSILON, return_parts=True)
+        assert torch.equal(zb[pos], z1[0]), f"batch {batch}: converged seeds differ from the single-field run"
+        assert torch.equal(sb[pos], s1[0])
+
+
 def test_full_size_properties(device):
     """480x640 (BASELINE config 3): determinism, purity against the generating partition,
     label 0 is the largest cluster, seed indices distinct and in range."""
