@@ -207,6 +207,15 @@ def parity_report(gpu_maps, cpu_npz, network=None, network_crop=None, device=Non
     from unseenobjectclustering_amd import runner
     from unseenobjectclustering_amd.fcn import test_dataset as TD
     worst, s1_exact, given_exact, used, given_bad = 0.0, True, True, 0, []
+    # the oracle's maps of the same frames from ANOTHER host (tests/golden/bench_oracle: the build container, 4 threads)
+    import glob
+    fixture = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "bench_oracle", "frames_*.npz"))):
+        zf = np.load(path)
+        if int(zf["first"]) < n:
+            for i in range(len(zf["final"])):
+                fixture[int(zf["first"]) + i] = zf["final"][i]
+    given_bad_fix, oracle_vs_fix = [], []
     for g in range(n):
         if not os.path.exists(os.path.join(embed_dir, f"f2_{g}.npy")):
             continue
@@ -225,6 +234,9 @@ def parity_report(gpu_maps, cpu_npz, network=None, network_crop=None, device=Non
         given_exact = given_exact and bool(O.labels_equal_up_to_permutation(out_b[0].numpy(), want1[g])) \
             and bool(O.labels_equal_up_to_permutation(fin_b, want[g]))
         given_bad.append(_mismatched_pixels(fin_b, want[g]))
+        if g in fixture:
+            given_bad_fix.append(_mismatched_pixels(fin_b, fixture[g]))
+            oracle_vs_fix.append(_mismatched_pixels(want[g], fixture[g]))
         # (c) stage 1 of the full HIP path
         np.random.seed(runner.frame_rng_seed(g))
         out_c, _ = TD.test_sample(dict(image_color=img, depth=dep), network, None)
@@ -232,9 +244,13 @@ def parity_report(gpu_maps, cpu_npz, network=None, network_crop=None, device=Non
     rep.update({"decomposed_frames": used, "embed_max_err": worst, "embed_tolerance": 1e-3,
                 "exact_given_oracle_embeddings": given_exact if used else None,
                 "given_oracle_embeddings_mismatched_pixels": given_bad, "stage1_exact": s1_exact if used else None,
+                "given_oracle_embeddings_mismatched_pixels_vs_fixture_oracle": given_bad_fix or None,
+                "this_oracle_run_vs_fixture_oracle_mismatched_pixels": oracle_vs_fix or None,
                 "note": "mismatched_pixels = end to end (HIP embeddings -> HIP integer path); *given_oracle_embeddings* = the "
                         "oracle's stage-1 and crop embeddings through the HIP clustering / ROI / match / paste kernels, against "
-                        "THIS run's oracle maps.  Bench frame 0 holds one pixel at which the oracle itself is not reproducible: "
+                        "THIS run's oracle maps; *_vs_fixture_oracle = against the same oracle run on another host "
+                        "(tests/golden/bench_oracle), and this_oracle_run_vs_fixture_oracle = the two oracle runs against each "
+                        "other.  Bench frame 0 holds one pixel at which the oracle itself is not reproducible: "
                         "its torch-CPU result differs between 1 and 4 threads on this host and between hosts "
                         "(profiles/r03_oracle_thread_sensitivity_gpu_box.json); against the committed 4-thread oracle fixture the "
                         "HIP integer path is bit-exact on all 24 frames tested (tests/test_headline_parity_gpu.py).  "
