@@ -221,6 +221,11 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
   W4_FRAG(0, 0, wa0, xb0)
   int s_cur = 0, s_nxt = 1, s_nn = 2;  // ring positions of chunks kc, kc+1, kc+2
   const bool early = wave < 4;         // waves w and w+4 share a SIMD: they issue their DMA bursts at different points
+  // The second-dispatched half of the block loses the issue arbitration against its SIMD partner (priority, then age:
+  // MI355X_MICROARCH.md, "Two waves per SIMD", item 4): one static priority bump for it, no per-phase flips.
+  // Measured alone: layer4 412 -> 402 us, 28-crop layer4 533 -> 528 us, the short-K shapes unchanged; in the
+  // three-stream pipeline neutral (160.9-161.2 frames/s either way, same-box A/B).
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
   for (int kc = 0; kc < nchunks; ++kc) {
     if (kc + 2 < nchunks && early) W4_ISSUE(s_nn)
     W4_MFMA_E(wa0, xb0, x)
