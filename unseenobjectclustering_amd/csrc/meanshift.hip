@@ -614,19 +614,40 @@ constexpr int EXP_STEPS = 7;
 // sched_barrier(0) after every slot keeps hipcc from regrouping.
 // ABL (timing ablations, dev only; results are wrong for ABL != 0): 1 = no exp arithmetic, 4 = S chains only,
 // 5 = accumulate MFMAs only.
-template <int ST, int ABL, int I>
-__device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&zb)[ST][4],
-                                         f32x4 (&acc)[ST][4], f32x4 (&Sv)[ST + 2], float (&wv)[ST + 2][4],
-                                         ExpState (&es)[4], float kappa) {
+//
+// QUAD: the last seed tile holds at most 4 seeds (m = 100 = 6 x 16 + 4) and runs on v_mfma_f32_4x4x1_16B_f32 — sixteen
+// independent 4x4 outer products per instruction, an eighth of the 16x16x4 instruction's time — instead of a padded
+// 16-seed tile (12 % of the kernel's MFMAs were that padding).  With block = (channel phase t/4, pixel group q):
+//   S:    A = xc (lane (t,q): pixel 4q + t%4, channel 16(t/4) + k), B = zb[last] loaded as Z[seed 16(ST-1) + t%4] in the
+//         same channels; D reg r = the partial dot product of pixel 4q+r with seed t%4 over the block's 16 channels; the
+//         four channel phases of a row meet through two DPP row rotations ((p0 + p2) + (p1 + p3) on every lane).
+//   The result has the layout of a regular tile's S (reg r <-> pixel 4q+r) with seed t%4 in place of seed t, so exp()
+//   and the accumulate step keep their code: acc[last][ct] += W[pixel 4q+r][seed i] X[pixel 4q+r][chan 4t+ct] with
+//   block = (channel group t/4, pixel group q), summed over the four pixel groups once per virtual block.
+template <int ST, int ABL, bool QUAD, int I>
+__device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&xc)[4],
+                                         const float4 (&zb)[ST][4], f32x4 (&acc)[ST][4], f32x4 (&Sv)[ST + 2],
+                                         float (&wv)[ST + 2][4], ExpState (&es)[4], float kappa) {
   // Sv / wv carry two spare rows so that the (never executed) I-1 / I-2 references of the first steps stay in range
   constexpr bool do_s = I < ST && ABL != 5, do_a = I >= 2 && ABL != 4, do_e = I >= 1 && I - 1 < ST;
   constexpr int IS = I < ST ? I : 0, IE = I >= 1 ? I - 1 : 0, IA = I >= 2 ? I - 2 : 0;
+  constexpr bool quad_s = QUAD && IS == ST - 1, quad_a = QUAD && IA == ST - 1;
   if (do_s) {
     Sv[IS] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int v = k >> 2, e = k & 3;
-      Sv[IS] = mfma4(f4c(xa[v], e), f4c(zb[IS][v], e), Sv[IS]);
+      if (quad_s)
+        Sv[IS] = __builtin_amdgcn_mfma_f32_4x4x1f32(f4c(xc[v], e), f4c(zb[IS][v], e), Sv[IS], 0, 0, 0);
+      else
+        Sv[IS] = mfma4(f4c(xa[v], e), f4c(zb[IS][v], e), Sv[IS]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (quad_s) {   // the four channel phases (lanes t, t+4, t+8, t+12 of a row): identical sum order on every lane
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Sv[IS][r] += dpp_f<0x128>(Sv[IS][r]);   // row_ror:8
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Sv[IS][r] += dpp_f<0x124>(Sv[IS][r]);   // row_ror:4
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -635,7 +656,10 @@ __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&x
   for (int k = 0; k < 16; ++k) {
     if (do_a) {
       const int r = k >> 2, ct = k & 3;
-      acc[IA][ct] = mfma4(wv[IA][r], f4c(xb[r], ct), acc[IA][ct]);
+      if (quad_a)
+        acc[IA][ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[IA][r], f4c(xb[r], ct), acc[IA][ct], 0, 0, 0);
+      else
+        acc[IA][ct] = mfma4(wv[IA][r], f4c(xb[r], ct), acc[IA][ct]);
     }
     // the VALU steps that belong behind this slot, in 4 clusters per seed tile (behind MFMAs 3, 7, 11, 15): every
     // MFMA -> VALU switch costs ~2.7 cycles on top of the VALU's own 2 (scripts/mfma_shadow.hip)
@@ -665,19 +689,20 @@ __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&x
   }
 }
 
-template <int ST, int ABL, int... Is>
-__device__ __forceinline__ void hcr_tile_steps(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&zb)[ST][4],
-                                               f32x4 (&acc)[ST][4], float kappa, std::integer_sequence<int, Is...>) {
+template <int ST, int ABL, bool QUAD, int... Is>
+__device__ __forceinline__ void hcr_tile_steps(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&xc)[4],
+                                               const float4 (&zb)[ST][4], f32x4 (&acc)[ST][4], float kappa,
+                                               std::integer_sequence<int, Is...>) {
   f32x4 Sv[ST + 2];
   float wv[ST + 2][4];
   ExpState es[4];
-  (hcr_step<ST, ABL, Is>(xa, xb, zb, acc, Sv, wv, es, kappa), ...);
+  (hcr_step<ST, ABL, QUAD, Is>(xa, xb, xc, zb, acc, Sv, wv, es, kappa), ...);
 }
 
-template <int ST, int ABL>
-__device__ __forceinline__ void hcr_tile(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&zb)[ST][4],
-                                         f32x4 (&acc)[ST][4], float kappa) {
-  hcr_tile_steps<ST, ABL>(xa, xb, zb, acc, kappa, std::make_integer_sequence<int, ST + 2>{});
+template <int ST, int ABL, bool QUAD>
+__device__ __forceinline__ void hcr_tile(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&xc)[4],
+                                         const float4 (&zb)[ST][4], f32x4 (&acc)[ST][4], float kappa) {
+  hcr_tile_steps<ST, ABL, QUAD>(xa, xb, xc, zb, acc, kappa, std::make_integer_sequence<int, ST + 2>{});
 }
 
 // THE SHIPPED KERNEL (UOC_HC_VARIANT=2, default): one wave per SIMD (4 waves per block, one block per CU), every wave
@@ -694,7 +719,7 @@ __device__ __forceinline__ void hcr_tile(const float4 (&xa)[4], const float4 (&x
 // reduction itself, ~2 us against ~70 us of tiles).
 // (Round 2's two-waves-per-SIMD variant with the seeds split between the waves measured the same 87.5 vs 88.0 us and
 // fetched X twice; it was removed in round 3 — fp32 MFMA and VALU share the SIMD's lanes, DESIGN.md.)
-template <int ST, int ABL = 0>
+template <int ST, int ABL = 0, bool QUAD = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void hc_iter_reg1_kernel(
     const float *__restrict__ X, int n, const float *__restrict__ Z, int m, float kappa, float *__restrict__ partial,
     int nvb) {
@@ -715,8 +740,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
   for (int i = 0; i < ST; ++i)
 #pragma unroll
-    for (int v = 0; v < 4; ++v)
-      zb[i][v] = *reinterpret_cast<const float4 *>(Z + (size_t)min(16 * i + t, m - 1) * C + 16 * v + 4 * q);
+    for (int v = 0; v < 4; ++v) {
+      if (QUAD && i == ST - 1)   // the 4x4x1 tile: seed 16(ST-1) + t%4, channels 16(t/4) + 4v .. +3
+        zb[i][v] = *reinterpret_cast<const float4 *>(Z + (size_t)min(16 * i + (t & 3), m - 1) * C + 16 * (t >> 2) + 4 * v);
+      else
+        zb[i][v] = *reinterpret_cast<const float4 *>(Z + (size_t)min(16 * i + t, m - 1) * C + 16 * v + 4 * q);
+    }
   f32x4 acc[ST][4];
 #pragma unroll
   for (int s = 0; s < ST; ++s)
@@ -727,7 +756,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int stride = nvb * 4;
   // Pixel tiles: branch-free loads (clamped row index).  A clamped xa row only produces a finite S / W for a pixel
   // whose xb row is zeroed, so out-of-range pixels contribute exactly 0; xb is zeroed only in the (rare) partial tile.
-  auto load_tile = [&](int tl, float4(&a)[4], float4(&bb)[4]) {
+  auto load_tile = [&](int tl, float4(&a)[4], float4(&bb)[4], float4(&cc)[4]) {
     const int base = min(tl, ntile - 1) * 16;
     const int pa = min(base + t, n - 1);
 #pragma unroll
@@ -736,6 +765,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int r = 0; r < 4; ++r) {
       const int pb = base + 4 * q + r;
       bb[r] = *reinterpret_cast<const float4 *>(X + (size_t)min(pb, n - 1) * C + 4 * t);
+    }
+    if (QUAD) {   // third view of the tile for the 4x4x1 S step: pixel 4q + t%4, channels 16(t/4) + 4v .. +3
+      const int pc = min(base + 4 * q + (t & 3), n - 1);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) cc[v] = *reinterpret_cast<const float4 *>(X + (size_t)pc * C + 16 * (t >> 2) + 4 * v);
     }
   };
   // applied when the tile becomes the current one (a select on freshly loaded data would force a wait at the load)
@@ -749,14 +783,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
   int vb = blockIdx.x;
   int held = vb * 4 + wave;   // the tile whose pixels sit in xa / xb
-  float4 xa[4], xb[4];
-  load_tile(held, xa, xb);
+  float4 xa[4], xb[4], xc[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) xc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  load_tile(held, xa, xb, xc);
   mask_tile(held, xb);
 #pragma unroll
   for (int i = 0; i < ST; ++i)
 #pragma unroll
     for (int v = 0; v < 4; ++v)
-      if (16 * i + t >= m) zb[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (16 * i + ((QUAD && i == ST - 1) ? (t & 3) : t) >= m) zb[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
 
   while (vb < nvb) {
     // The loads of the wave's NEXT tile (the first tile of the next virtual block behind the last one of this block)
@@ -766,10 +802,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // opaque v_mov and a sched_barrier keeps the loads above the first MFMA.
     for (int tile = vb * 4 + wave; tile < ntile; tile += stride) {   // invariant: held == tile
       const int nxt = tile + stride < ntile ? tile + stride : (vb + (int)gridDim.x) * 4 + wave;
-      float4 na[4], nb[4];
-      load_tile(nxt, na, nb);
+      float4 na[4], nb[4], nc[4];
+      load_tile(nxt, na, nb, nc);
       __builtin_amdgcn_sched_barrier(0);
-      hcr_tile<ST, ABL>(xa, xb, zb, acc, kappa);
+      hcr_tile<ST, ABL, QUAD>(xa, xb, xc, zb, acc, kappa);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
@@ -779,10 +815,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                      : "=&v"(xb[v].x), "=&v"(xb[v].y), "=&v"(xb[v].z), "=&v"(xb[v].w)
                      : "v"(nb[v].x), "v"(nb[v].y), "v"(nb[v].z), "v"(nb[v].w));
       }
+      if (QUAD) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                       : "=&v"(xc[v].x), "=&v"(xc[v].y), "=&v"(xc[v].z), "=&v"(xc[v].w)
+                       : "v"(nc[v].x), "v"(nc[v].y), "v"(nc[v].z), "v"(nc[v].w));
+      }
       mask_tile(nxt, xb);
       held = nxt;
     }
     // ---- this virtual block is complete: the four waves' accumulators meet in LDS, (w0 + w1) + (w2 + w3) ----
+    if (QUAD) {   // the 4x4x1 tile's accumulators are partial over the pixel groups q: lanes l, l^16, l^32, l^48 -> (q0+q1)+(q2+q3)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[ST - 1][ct][r];
+          v += __shfl_xor(v, 16);
+          v += __shfl_xor(v, 32);
+          acc[ST - 1][ct][r] = v;      // every lane now holds the total; lanes q = 0 are seeds 16(ST-1) .. +3, the rest is
+        }                              // written to rows >= m of the partial, which nobody reads
+    }
 #pragma unroll
     for (int s = 0; s < ST; ++s)
 #pragma unroll
@@ -812,7 +866,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // (only a wave that had no tile in the finished block — tiny fields — does not hold the next block's first tile yet)
     if (held != first) {
       held = first;
-      load_tile(held, xa, xb);
+      load_tile(held, xa, xb, xc);
       mask_tile(held, xb);
     }
   }
@@ -1407,7 +1461,25 @@ static void launch_hc(const float *X, int batch, int n, float *Z, int m, float k
           else if (ST == 7 && abl == 5) go(hc_iter_reg1_kernel<ST, (ST == 7 ? 5 : 0)>);
           else
 #endif
-            hipLaunchKernelGGL((hc_iter_reg1_kernel<ST, 0>), g, bdim, lds_reg, st, X, n, Z, m, kappa, w.hc_partial, nvb);
+          {
+            static int quad_ok = -1;
+            if (quad_ok < 0) {
+              const char *e = getenv("UOC_HC_QUAD");   // A/B: 0 = the last seed tile as a padded 16-seed tile (rounds 2-3a)
+              quad_ok = e ? atoi(e) : 1;
+            }
+            const int last = m - 16 * (ST - 1);      // seeds in the last tile
+            if (quad_ok && ST >= 2 && last >= 1 && last <= 4) {
+              static DeviceOnce attr_q;
+              if (!attr_q.done() && lds_reg > 64 * 1024) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hc_iter_reg1_kernel<ST, 0, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+                attr_q.mark();
+              }
+              hipLaunchKernelGGL((hc_iter_reg1_kernel<ST, 0, true>), g, bdim, lds_reg, st, X, n, Z, m, kappa, w.hc_partial, nvb);
+            } else {
+              hipLaunchKernelGGL((hc_iter_reg1_kernel<ST, 0, false>), g, bdim, lds_reg, st, X, n, Z, m, kappa, w.hc_partial, nvb);
+            }
+          }
         }
       }
       if (!reg)
