@@ -207,10 +207,11 @@ def test_persistent_and_streaming_seed_selection_agree(device, shape, batch):
     assert torch.equal(i1, i0) and torch.equal(l1, l0)
 
 
-@pytest.mark.parametrize("n,m", [(50, 100), (1, 100), (200, 1), (130, 128), (4097, 17)])
+@pytest.mark.parametrize("n,m", [(50, 100), (1, 100), (200, 1), (130, 128), (4097, 17), (300, 34), (515, 51), (77, 68)])
 def test_ragged_and_tiny_inputs_vs_oracle(device, n, m):
     """Fewer points than seeds (duplicate seeds, every distance ties), a single point, a single seed,
-    the maximum seed count, and sizes that are not multiples of any tile."""
+    the maximum seed count, sizes that are not multiples of any tile, and seed counts whose last tile holds 1 - 4 seeds
+    (17, 34, 51, 68: that tile runs on the 4x4x1 matrix instruction, csrc/meanshift.hip QUAD)."""
     rng = np.random.default_rng(n * 1000 + m)
     c = rng.standard_normal((3, 64)).astype(np.float32)
     x = c[rng.integers(0, 3, n)] + 0.05 * rng.standard_normal((n, 64)).astype(np.float32)
