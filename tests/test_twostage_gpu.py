@@ -163,7 +163,13 @@ def test_bench_json_contract(device):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
     assert len(lines) == 1
+    # the driver keeps only a few KB of output tail (stdout AND stderr): round 3's 22.7 KB line was cut and the record lost
+    assert len(lines[0]) < 3000, len(lines[0])
+    assert len(out.stderr) < 3000, "stderr shares the driver's output tail with the JSON line"
     d = json.loads(lines[0])
+    full = json.load(open(os.path.join(root, d["full"])))
+    assert full["value"] == d["value"] and full["conv_by_shape"] and full["kernels"] and full["clustering_by_shape"]
+    assert d["latency"]["frames_per_s"] > 1 and d["sustained_frames_per_s"] > 1 and d["pcie_inclusive_frames_per_s"] > 1
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -172,7 +178,8 @@ def test_bench_json_contract(device):
     assert "workload" in d["config"] and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    f = d["frame_roofline"]
+    f = full["frame_roofline"]
+    assert d["frame_roofline"]["hbm_frac"] == f["hbm_frac"]
     assert 0 < f["hbm_frac"] < 1 and 0 < f["mfma_frac"] < 1 and f["rois_per_frame"] >= 1
     assert abs(f["algorithmic_gb"] - (8.98 + 1.43 * f["rois_per_frame"])) < 0.02
     c = d["cpu_baseline"]
