@@ -39,6 +39,9 @@ int uoc_version(void);
  * different streams).  Optional; call it before process exit while the HIP runtime is still up.  Idempotent. */
 int uoc_shutdown(void);
 const char *uoc_last_error(void);
+/* The library reads its development knobs (UOC_* environment variables) once and caches them; a process that changes
+ * one afterwards (tests, micro-benchmarks) calls this to have them read again at their next use. */
+int uoc_reload_env(void);
 
 /* ------------------------------------------------------------------------------------------
  * Mean-shift clustering  — replaces lib/utils/mean_shift.py:128-229 (cosine metric)

@@ -172,13 +172,71 @@ def test_winograd_conv_vs_torch_cpu(device, case, algo):
     L = _native.lib()
     os.environ["UOC_CONV_WINOGRAD"] = "1" if algo == "f2" else "4"
     os.environ["UOC_WINO4_GEMM"] = "1" if algo == "f4-planes-as-groups" else "2"
+    L.uoc_reload_env()           # the library caches its development knobs
     try:
         rc = L.uoc_conv2d_nhwc(_native.ptr(xd), _native.ptr(wd), _native.ptr(bd), _native.ptr(rd), _native.ptr(out),
                                G, B, H, W, Cin, Cout, 3, 1, dil, dil, int(relu), _native.stream_ptr(device))
     finally:
         os.environ.pop("UOC_CONV_WINOGRAD", None)
         os.environ.pop("UOC_WINO4_GEMM", None)
+        L.uoc_reload_env()
     _native.check(rc, "uoc_conv2d_nhwc (winograd)")
     got = out.cpu().permute(0, 1, 4, 2, 3)
     err = (got - ref).abs().max().item()
     assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
+
+
+def _wino4_conv(device, x, w, b, res, dil, relu, env=None):
+    """uoc_conv2d_nhwc with the F(4x4) hook on; x [G,B,Cin,H,W], w [G,Cout,Cin,3,3], b [G,Cout] | None -> [G,B,Cout,H,W] (CPU)."""
+    G, B, Cin, H, W = x.shape
+    Cout = w.shape[1]
+    xd = x.permute(0, 1, 3, 4, 2).contiguous().to(device)
+    wd = w.permute(0, 3, 4, 1, 2).reshape(G, 9, Cout, Cin).contiguous().to(device)
+    bd = b.to(device) if b is not None else None
+    rd = res.permute(0, 1, 3, 4, 2).contiguous().to(device) if res is not None else None
+    out = torch.empty((G, B, H, W, Cout), device=device)
+    L = _native.lib()
+    os.environ["UOC_CONV_WINOGRAD"] = "4"
+    for k, v in (env or {}).items():
+        os.environ[k] = v
+    L.uoc_reload_env()
+    try:
+        rc = L.uoc_conv2d_nhwc(_native.ptr(xd), _native.ptr(wd), _native.ptr(bd), _native.ptr(rd), _native.ptr(out),
+                               G, B, H, W, Cin, Cout, 3, 1, dil, dil, int(relu), _native.stream_ptr(device))
+    finally:
+        os.environ.pop("UOC_CONV_WINOGRAD", None)
+        for k in (env or {}):
+            os.environ.pop(k, None)
+        L.uoc_reload_env()
+    _native.check(rc, "uoc_conv2d_nhwc (winograd F(4x4) hook)")
+    return out.cpu().permute(0, 1, 4, 2, 3)
+
+
+def test_winograd4_edge_cases(device):
+    """(a) Cout = 192 (Cout / 64 not a power of two) must take the direct kernel instead of failing in the plane
+    GEMM; (b) a null bias is zero on the Winograd path as on the direct one; (c) a batch whose frequency planes exceed the
+    32-bit offset range is run as slices of the batch — forced here with UOC_WINO4_MAX_MB — with bit-identical results."""
+    g = torch.Generator().manual_seed(77)
+    # (a)
+    x = torch.randn(1, 2, 128, 20, 24, generator=g)
+    w = torch.randn(1, 192, 128, 3, 3, generator=g) / np.sqrt(128 * 9)
+    b = torch.randn(1, 192, generator=g)
+    ref = F.relu(F.conv2d(x[0], w[0], b[0], padding=1))
+    got = _wino4_conv(device, x, w, b, None, 1, True)[0]
+    assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    # (b)
+    x = torch.randn(2, 1, 128, 20, 24, generator=g)
+    w = torch.randn(2, 128, 128, 3, 3, generator=g) / np.sqrt(128 * 9)
+    ref = torch.stack([F.conv2d(x[i], w[i], None, padding=2, dilation=2) for i in range(2)])
+    got = _wino4_conv(device, x, w, None, None, 2, False)
+    assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+    # (c) 5 images of 28x28, 256 channels, d = 2: 72 planes x 49 tiles x 256 x 4 B = 3.4 MB per image -> slices of 2, 2, 1
+    x = torch.randn(2, 5, 256, 28, 28, generator=g)
+    w = torch.randn(2, 256, 256, 3, 3, generator=g) / np.sqrt(256 * 9)
+    b = torch.randn(2, 256, generator=g)
+    res = torch.randn(2, 5, 256, 28, 28, generator=g)
+    whole = _wino4_conv(device, x, w, b, res, 2, True)
+    sliced = _wino4_conv(device, x, w, b, res, 2, True, env={"UOC_WINO4_MAX_MB": "8"})
+    assert torch.equal(whole, sliced)
+    ref = F.relu(torch.stack([F.conv2d(x[i], w[i], b[i], padding=2, dilation=2) for i in range(2)]) + res)
+    assert (whole - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())

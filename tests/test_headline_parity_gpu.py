@@ -11,8 +11,13 @@ nearest clusters are equally far.  The tests therefore split the claim exactly t
   (a) embeddings: the HIP networks against the oracle's, on the stage-1 frames AND on the oracle's own crops  <= 1e-3
   (b) integer path: the ORACLE's embeddings (stage 1 and every crop) fed through the HIP clustering + ROI / match / paste
       kernels must reproduce the oracle's label maps bit-exactly — on every bench frame tested, no tolerance
-  (c) end to end (HIP embeddings -> HIP integer path): a measured mismatch histogram over the frames of
-      tests/golden/bench_oracle/ (default: the first 256 of its 1 024), asserted against the measured bounds
+  (c) end to end (HIP embeddings -> HIP integer path) over all 1 024 frames of tests/golden/bench_oracle/: every pixel that
+      differs from the oracle's map must be a near-tie of the ORACLE's own run — nearest-seed margin (oracle/margins.py,
+      committed per frame in tests/golden/bench_margins/) at most TAU — and ZERO pixels may differ beyond it
+  (d) TAU is not a free parameter: the margin of a pixel between seeds a and b moves by at most |dx| + (|dz_a| + |dz_b|) / 2
+      when its embedding moves by dx and the seeds by dz (L2 norms, unit vectors); (d) measures |dx| (HIP vs oracle
+      embeddings) and |dz| (HIP vs oracle converged seeds, i.e. the embedding error through ten kappa = 20 iterations)
+      on live oracle runs and asserts their sum stays below TAU
 
 The oracle's label maps come from tests/golden/bench_oracle/*.npz (tests/golden/make_bench_oracle.py: oracle runs in the
 build container, 1024 frames); the oracle's two network passes per frame run here on the host cores.  Reports go to
@@ -37,9 +42,7 @@ DECOMPOSED_FRAMES = int(os.environ.get("UOC_PARITY_FRAMES", "24"))     # frames 
 # measured bounds of the end-to-end comparison (profiles/r03_parity_histogram.json, 1 024 frames: 958 identical up to
 # permutation, 39 x 1, 12 x 2, 7 x 3, 3 x 4, 3 x 5 pixels, one frame 17 and one 24 pixels of 307 200 — and on those worst
 # frames the integer path is bit-exact given the oracle's embeddings, profiles/r03_parity_decomposed_outlier_frames.json)
-E2E_MIN_EXACT_FRACTION = 0.90          # share of frames identical up to a permutation of the ids (measured 0.936)
-E2E_P99_MISMATCHED_PIXELS = 5          # 99 % of the frames differ by at most this many pixels (measured: 99.8 %)
-E2E_MAX_MISMATCHED_PIXELS = 32         # worst frame (measured 24 = 0.008 % of a frame)
+E2E_MIN_EXACT_FRACTION = 0.90          # secondary alarm only: share of frames identical up to a permutation (measured 0.936)
 
 
 def _fixture():
@@ -135,43 +138,185 @@ def test_embeddings_and_integer_path_separately(device, nets):
         assert r["given_oracle_embeddings"]["final_exact_up_to_permutation"], r
 
 
-def test_end_to_end_mismatch_histogram(device, nets):
-    """(c): HIP embeddings -> HIP integer path over every frame of the fixture, through the frame-parallel runner in the
-    launch shape bench.py times (streams x frames per launch), against the oracle's final maps."""
+def _margins():
+    """frame index -> near-tie sets of the oracle's stage-1 and final maps (tests/golden/bench_margins, written by
+    tests/golden/make_bench_margins.py with oracle/margins.py): dict(idx1, val1, idxF, valF, rois, slack)."""
+    out = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "bench_margins", "frames_*.npz"))):
+        z = np.load(path)
+        first = int(z["first"])
+        for i in range(int(z["count"])):
+            rec = {}
+            for k in ("idx1", "val1", "idxF", "valF", "rois"):
+                o = z["off_" + k]
+                rec[k] = z[k][o[i]:o[i + 1]]
+            rec["rois"] = rec["rois"].reshape(-1, 4).astype(np.int64)
+            rec["slack"] = z["slack"][i]
+            out[first + i] = rec
+    return out
+
+
+def _mismatching_pixels(a, b):
+    """Flat indices of the pixels on which partition `a` disagrees with `b` under the best one-to-one relabelling."""
+    from scipy.optimize import linear_sum_assignment
+    a, b = np.asarray(a).reshape(-1).astype(np.int64), np.asarray(b).reshape(-1).astype(np.int64)
+    if np.array_equal(a, b):
+        return np.zeros(0, np.int64)
+    kb = int(b.max()) + 1
+    table = np.bincount(a * kb + b, minlength=(int(a.max()) + 1) * kb).reshape(-1, kb)
+    r, c = linear_sum_assignment(-table)
+    to_b = np.full(table.shape[0], -1, np.int64)
+    to_b[r] = c
+    return np.nonzero(to_b[a] != b)[0]
+
+
+def _lookup(idx, val, pix):
+    """Margins of the pixels `pix` in a sparse near-tie set (idx sorted ascending); +inf = not in the set (> TAU_STORE)."""
+    out = np.full(len(pix), np.inf, np.float64)
+    if len(idx):
+        pos = np.clip(np.searchsorted(idx, pix), 0, len(idx) - 1)
+        hit = idx[pos] == pix
+        out[hit] = val[pos[hit]]
+    return out
+
+
+def _frames_on_host(indices):
+    return [synth.palette_frame(10_000 + g, H, W, 5 + (10_000 + g) % 3) for g in indices]
+
+
+def _frame_pair(g):
+    fr = synth.palette_frame(10_000 + g, H, W, 5 + (10_000 + g) % 3)
+    return fr["image_color"], fr["depth"]
+
+
+def test_end_to_end_margin_bounded(device, nets):
+    """(c) north_star's "integer labels bit-exact up to label permutation" in the only form fp32 allows, on every frame
+    of BASELINE configs[4] (1 024 by default): HIP embeddings -> HIP integer path through the frame-parallel runner in
+    the launch shape bench.py times, against the oracle's final maps — and EVERY pixel that differs must be one whose
+    decision the reference's own arithmetic does not resolve: its nearest-seed margin in the oracle's run (oracle's
+    embeddings, oracle's converged seeds, mean_shift.py:211-214 through the paste of test_dataset.py:172-177) is at most
+    TAU.  Zero pixels may differ with a margin above TAU."""
+    from concurrent.futures import ProcessPoolExecutor
+    import multiprocessing as mp
+    from oracle import margins as M
     sd, net, net_crop = nets
-    fix = _fixture()
+    fix, mar = _fixture(), _margins()
     n = 0
-    while n in fix:
+    while n in fix and n in mar:
         n += 1
-    # default: the first 256 frames (~1 min, most of it generating the synthetic frames on the host);
-    # UOC_PARITY_E2E_FRAMES=1024 = all of BASELINE configs[4]'s frames -> profiles/r03_parity_histogram.json
-    n = min(n, int(os.environ.get("UOC_PARITY_E2E_FRAMES", "256")))
-    assert n >= 8, "tests/golden/bench_oracle/ is missing"
-    hist, worst, per_frame = {}, 0, []
+    n = min(n, int(os.environ.get("UOC_PARITY_E2E_FRAMES", "1024")))
+    assert n >= 8, "tests/golden/bench_oracle/ or bench_margins/ is missing"
     CH = 64                                   # frames resident at a time (7.4 MB each)
-    for lo in range(0, n, CH):
-        hi = min(n, lo + CH)
-        samples = []
-        for g in range(lo, hi):
-            img, dep = _bench_frame(g)
-            samples.append(dict(image_color=img.to(device), depth=dep.to(device)))
-        fn = runner.two_stage_frame_fn(samples, net, net_crop, first_index=lo, frames_per_launch=4)
-        # run_sharded as "rank lo/CH of ceil(n/CH)": exactly the global frames [lo, hi) (their RNG seeds are global), no
-        # collective — the same call a rank of bench.py --gpus N makes for its block
-        maps = runner.run_sharded(n, fn, H, W, device, lo // CH, (n + CH - 1) // CH, False, inflight=3).cpu().numpy()
-        assert len(maps) == hi - lo
-        for g in range(lo, hi):
-            bad = _mismatch(maps[g - lo], fix[g][1])
-            per_frame.append(bad)
-            hist[bad] = hist.get(bad, 0) + 1
-            worst = max(worst, bad)
+    hist, per_frame, pixels, beyond, worst_margin = {}, [], [], [], 0.0
+    workers = max(1, min(32, len(os.sched_getaffinity(0)) - 2))
+    with ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as pool:     # spawn: this process holds a HIP context
+        chunks = [(lo, min(n, lo + CH)) for lo in range(0, n, CH)]
+        pending = pool.map(_frame_pair, range(0, n), chunksize=4)       # host-side synthesis runs ahead of the GPU
+        for lo, hi in chunks:
+            samples = []
+            for g in range(lo, hi):
+                img, dep = next(pending)
+                samples.append(dict(image_color=torch.from_numpy(img).to(device), depth=torch.from_numpy(dep).to(device)))
+            fn = runner.two_stage_frame_fn(samples, net, net_crop, first_index=lo, frames_per_launch=4)
+            maps = runner.run_sharded(n, fn, H, W, device, gather=False, inflight=3, block_range=(lo, hi)).cpu().numpy()
+            assert len(maps) == hi - lo
+            for g in range(lo, hi):
+                bad = _mismatching_pixels(maps[g - lo], fix[g][1])
+                per_frame.append(len(bad))
+                hist[len(bad)] = hist.get(len(bad), 0) + 1
+                if len(bad) == 0:
+                    continue
+                m = _lookup(mar[g]["idxF"], mar[g]["valF"], bad)
+                over = m > M.TAU
+                if over.any():
+                    # the one legitimate cascade: a stage-1 near-tie pixel that sits on a label's bounding box moves the
+                    # padded ROI (test_dataset.py:78-90), the crop is resampled on another grid and stage 2 starts from
+                    # different inputs.  Accept it only if it is exactly that.
+                    np.random.seed(runner.frame_rng_seed(g))
+                    out1, _ = TD.test_sample(dict(image_color=samples[g - lo]["image_color"].cpu(), depth=samples[g - lo]["depth"].cpu()), net, None)
+                    bad1 = _mismatching_pixels(out1[0].numpy(), fix[g][0])
+                    m1 = _lookup(mar[g]["idx1"], mar[g]["val1"], bad1)
+                    _, boxes = GO.roi_boxes(out1[0])
+                    moved = [k for k in range(len(mar[g]["rois"])) if k >= len(boxes) or not np.array_equal(boxes[k].numpy(), mar[g]["rois"][k])]
+                    ok = len(bad1) > 0 and bool((m1 <= M.TAU).all()) and len(boxes) == len(mar[g]["rois"]) and len(moved) > 0
+                    if ok:      # every beyond-margin pixel must lie inside a moved ROI window (old or new box)
+                        yy, xx = np.divmod(bad[over], W)
+                        inside = np.zeros(len(yy), bool)
+                        for k in moved:
+                            for x0, y0, x1, y1 in (mar[g]["rois"][k], boxes[k].numpy()):
+                                inside |= (xx >= x0) & (xx <= x1) & (yy >= y0) & (yy <= y1)
+                        ok = bool(inside.all())
+                    cls = "roi_moved_by_stage1_near_tie" if ok else "BEYOND_MARGIN"
+                    if not ok:
+                        beyond.append({"frame": g, "pixels": int(over.sum()), "stage1_mismatches": int(len(bad1)),
+                                       "stage1_margins": [float(v) for v in m1[:16]]})
+                else:
+                    cls = "near_tie"
+                    worst_margin = max(worst_margin, float(m.max()))
+                for p, v in zip(bad.tolist(), m.tolist()):
+                    pixels.append({"frame": g, "y": p // W, "x": p % W, "margin": (round(v, 9) if np.isfinite(v) else None), "class": cls})
     exact = hist.get(0, 0) / n
-    out = {"frames": n, "histogram_mismatched_pixels": {str(k): hist[k] for k in sorted(hist)}, "worst_frame": worst,
-           "exact_fraction": exact, "total_mismatched_pixels": int(sum(per_frame)), "pixels": n * H * W,
-           "per_frame": per_frame}
+    out = {"frames": n, "tau": M.TAU, "mismatching_pixels": len(pixels), "pixels_total": n * H * W,
+           "mismatches_beyond_margin": int(sum(b["pixels"] for b in beyond)), "largest_margin_of_a_mismatch": worst_margin,
+           "frames_with_a_moved_roi": sorted({p["frame"] for p in pixels if p["class"] == "roi_moved_by_stage1_near_tie"}),
+           "exact_fraction": exact, "histogram_mismatched_pixels": {str(k): hist[k] for k in sorted(hist)},
+           "beyond": beyond, "pixels": pixels, "per_frame": per_frame}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "parity_histogram.json"), "w"))
-    print(json.dumps({k: v for k, v in out.items() if k != "per_frame"}))
-    assert worst <= E2E_MAX_MISMATCHED_PIXELS, out["histogram_mismatched_pixels"]
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "parity_margins.json"), "w"))
+    print(json.dumps({k: v for k, v in out.items() if k not in ("per_frame", "pixels")}))
+    assert not beyond, beyond                                   # the claim: nothing differs beyond the margin
+    assert worst_margin <= M.TAU
+    # secondary (a coarse regression alarm, not the claim): most frames are identical outright
     assert exact >= E2E_MIN_EXACT_FRACTION, out["histogram_mismatched_pixels"]
-    assert sum(1 for v in per_frame if v <= E2E_P99_MISMATCHED_PIXELS) >= 0.99 * n, out["histogram_mismatched_pixels"]
+
+
+AMP_FRAMES = int(os.environ.get("UOC_PARITY_AMP_FRAMES", "3"))
+
+
+def test_tau_is_the_measured_perturbation(device, nets):
+    """(d) the perturbation that TAU stands for, measured: the oracle's full two-stage run (oracle/margins) on the host
+    next to the HIP kernels on the first AMP_FRAMES bench frames.  Reports, for stage 1 and for the crops,
+      dx            max L2 error of a pixel's embedding (HIP network vs oracle network, same inputs)
+      dz_kernel     max L2 distance of a converged seed, HIP hill climbing vs oracle, SAME (oracle) embeddings
+      dz            the same with the HIP embeddings: dx amplified by ten kappa = 20 iterations
+    and asserts dx + dz <= TAU.  Also checks the oracle run on THIS host against the committed near-tie sets."""
+    from oracle import margins as M
+    from unseenobjectclustering_amd.utils import mean_shift as MS
+    sd, net, net_crop = nets
+    mar = _margins()
+    cpu_net = lambda image, label, depth: BO.segnet_forward(sd, image, depth)
+    rows = []
+    for g in range(AMP_FRAMES):
+        img, dep = _bench_frame(g)
+        rng = np.random.RandomState(runner.frame_rng_seed(g))
+        firsts = np.random.RandomState(runner.frame_rng_seed(g))
+        out, refined, info = M.test_sample_with_margins(img, dep, cpu_net, cpu_net, rng)
+        K = info["X2"].shape[0]
+        first1 = [int(firsts.randint(0, H * W))]
+        first2 = [int(firsts.randint(0, 224 * 224)) for _ in range(K)]
+        rgb_c, mask_c, rois, dep_c = GO.crop_rois(img, out.clone(), dep)
+        e1 = net(img.to(device), None, dep.to(device))                       # [1, 64, H, W] view of pixel-major rows
+        e2 = net_crop(rgb_c.to(device), None, dep_c.to(device))
+        X1h = e1[0].permute(1, 2, 0).reshape(-1, 64).contiguous()
+        X2h = e2.permute(0, 2, 3, 1).reshape(K, -1, 64).contiguous()
+        row = {"frame": g, "rois": K}
+        for tag, Xh, Xo, Zo, first in (("stage1", X1h[None], info["X1"][None], info["Z1"][None], first1),
+                                       ("crops", X2h, info["X2"], info["Z2"], first2)):
+            dx = float((Xh.cpu() - Xo).norm(dim=-1).max())
+            _, _, Zk, _ = MS.cluster_batch(Xo.to(device), first, 20.0, 100, 10, 0.04, return_parts=True)
+            _, _, Zh, _ = MS.cluster_batch(Xh, first, 20.0, 100, 10, 0.04, return_parts=True)
+            row[tag] = {"dx": dx, "dz_kernel": float((Zk.cpu() - Zo).norm(dim=-1).max()), "dz": float((Zh.cpu() - Zo).norm(dim=-1).max())}
+            row[tag]["amplification"] = row[tag]["dz"] / max(dx, 1e-12)
+        # the oracle on this host against the committed near-tie sets (made in the build container): same pixels below
+        # TAU_STORE / 2 (the edge of the stored set may move by an ulp of the margin)
+        idxF, valF = M.sparse_below(info["marginF"], M.TAU_STORE / 2)
+        stored = _lookup(mar[g]["idxF"], mar[g]["valF"], idxF.astype(np.int64))
+        row["near_tie_set_reproduced"] = bool(np.isfinite(stored).all() and np.abs(stored - valF).max() < 1e-4)
+        rows.append(row)
+    worst = max(r[t]["dx"] + r[t]["dz"] for r in rows for t in ("stage1", "crops"))
+    out = {"tau": M.TAU, "worst_dx_plus_dz": worst, "frames": rows}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "parity_tau.json"), "w"), indent=1)
+    print(json.dumps(out))
+    assert worst <= M.TAU, out
+    assert all(r["near_tie_set_reproduced"] for r in rows), rows

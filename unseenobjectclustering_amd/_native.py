@@ -19,6 +19,8 @@ def _declare(lib):
     P = c_void_p
     lib.uoc_version.restype = c_int
     lib.uoc_shutdown.restype = c_int
+    lib.uoc_reload_env.argtypes = []
+    lib.uoc_reload_env.restype = c_int
     lib.uoc_shutdown.argtypes = []
     lib.uoc_last_error.restype = c_char_p
     lib.uoc_ms_set_persistent_fps.argtypes = [c_int]
@@ -85,7 +87,7 @@ def _declare(lib):
 
 # every symbol include/uoc_hip.h declares (tests check the .so exports them all)
 EXPORTED_SYMBOLS = (
-    "uoc_version", "uoc_shutdown", "uoc_last_error", "uoc_ms_set_persistent_fps", "uoc_ms_set_stream_ordering", "uoc_ms_fps_fallbacks", "uoc_ms_check", "uoc_ms_workspace_bytes", "uoc_ms_select_seeds", "uoc_ms_select_seeds_from", "uoc_ms_hill_climb",
+    "uoc_version", "uoc_shutdown", "uoc_last_error", "uoc_reload_env", "uoc_ms_set_persistent_fps", "uoc_ms_set_stream_ordering", "uoc_ms_fps_fallbacks", "uoc_ms_check", "uoc_ms_workspace_bytes", "uoc_ms_select_seeds", "uoc_ms_select_seeds_from", "uoc_ms_hill_climb",
     "uoc_ms_seed_components", "uoc_ms_assign", "uoc_ms_cluster", "uoc_ms_workspace_bytes_wide", "uoc_ms_cluster_wide",
     "uoc_net_embed_dim",
     "uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",

@@ -1,6 +1,7 @@
 // libuoc_hip.so — error channel and version of the C ABI (include/uoc_hip.h).
 #include "common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 namespace uoc {
@@ -12,9 +13,24 @@ void set_error(const char *fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+std::atomic<int> g_env_epoch{0};
+int EnvInt::get() {
+  const int e = g_env_epoch.load(std::memory_order_acquire);
+  if (seen.load(std::memory_order_acquire) != e) {
+    const char *s = getenv(name);
+    val.store(s ? atoi(s) : def, std::memory_order_relaxed);
+    seen.store(e, std::memory_order_release);
+  }
+  return val.load(std::memory_order_relaxed);
+}
 }  // namespace uoc
 
 extern "C" {
-int uoc_version(void) { return 100; }
+int uoc_version(void) { return 101; }
+int uoc_reload_env(void) {
+  uoc::g_env_epoch.fetch_add(1, std::memory_order_acq_rel);
+  return UOC_OK;
+}
 const char *uoc_last_error(void) { return uoc::g_err; }
 }

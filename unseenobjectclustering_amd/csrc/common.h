@@ -32,6 +32,18 @@ void set_error(const char *fmt, ...);
 
 #define UOC_LAUNCH_CHECK() UOC_HIP_CHECK(hipGetLastError())
 
+// Development knobs from the environment, read ONCE (not per launch): the value is cached until uoc_reload_env() bumps
+// the epoch (tests / micro-benchmarks that switch a knob inside one process call that).
+extern std::atomic<int> g_env_epoch;
+struct EnvInt {
+  const char *name;
+  int def;
+  std::atomic<int> seen{-1};
+  std::atomic<int> val{0};
+  EnvInt(const char *n, int d) : name(n), def(d) {}
+  int get();
+};
+
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -36,6 +36,7 @@ int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_
 // Winograd F(4x4,3x3) path (csrc/wino4.hip): U = transformed weights [G*36][Cout][Cin] (launch_wino4_weights, computed
 // in double), ws = scratch of wino4_ws_floats() floats (the V and M frequency planes).
 bool wino4_eligible(const ConvParams &p);
+bool wino4_channels_ok(int Cin, int Cout);
 size_t wino4_ws_floats(int G, int B, int H, int W, int d, int Cin, int Cout);
 int launch_wino4_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st);
 int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_t st);

@@ -173,7 +173,9 @@ static int finalize_layer(uoc_net *n, ConvLayer &L) {
   // Static, not autotuned: the two algorithms round differently, and results must not depend on timing.
   if (!L.stem && L.K == 3 && L.stride == 1 && n->wino_min_cin > 0 && L.Cin >= n->wino_min_cin && L.Cin % 32 == 0 &&
       L.Cout % 64 == 0) {
-    if (n->wino_f == 4) {
+    if (n->wino_f == 4 && !wino4_channels_ok(L.Cin, L.Cout)) {
+      // the direct kernel runs this layer (run_conv asks wino4_eligible again)
+    } else if (n->wino_f == 4) {
       UOC_HIP_CHECK(hipMalloc(&L.d_U4, (size_t)G * 36 * L.Cout * L.Cin * sizeof(float)));
       if (int rc = launch_wino4_weights(L.d_w, L.d_U4, G, L.Cout, L.Cin, nullptr)) return rc;
     } else {

@@ -343,9 +343,17 @@ static void pick_wino4_tile(int NT, int Cout, int planes, int &bm, int &bn, int 
 static int launch_wino4_gemm(const float *V, const float *U, float *Mo, int NT, int Cin, int Cout, int planes, hipStream_t st) {
   int bm, bn, nblocks;
   pick_wino4_tile(NT, Cout, planes, bm, bn, nblocks);
-  if (const char *e = getenv("UOC_WINO4_TILE")) {  // dev: "BMxBN"
-    int a = 0, b = 0;
-    if (sscanf(e, "%dx%d", &a, &b) == 2 && (b == 64 || b == 128) && Cout % b == 0) {
+  static int env_bm = -1, env_bn = 0;   // dev knob "BMxBN", read once
+  if (env_bm < 0) {
+    env_bm = 0;
+    if (const char *e = getenv("UOC_WINO4_TILE")) {
+      int a = 0, b = 0;
+      if (sscanf(e, "%dx%d", &a, &b) == 2 && (b == 64 || b == 128)) env_bm = a, env_bn = b;
+    }
+  }
+  if (env_bm > 0) {
+    const int a = env_bm, b = env_bn;
+    if (Cout % b == 0) {
       bm = a;
       bn = b;
       const int ncu = device_num_cu() > 0 ? device_num_cu() : 256;
@@ -363,8 +371,15 @@ static int launch_wino4_gemm(const float *V, const float *U, float *Mo, int NT, 
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
+// Cout / 64 must be a power of two: the plane GEMM splits an item index into (m-tile, n-tile) with a shift (ResNet34: 128,
+// 256, 512).  Other widths (192, 320, 384 ...) take the direct kernel.
+bool wino4_channels_ok(int Cin, int Cout) {
+  const int n64 = Cout / 64;
+  return Cin % W4BK == 0 && Cout % 64 == 0 && n64 > 0 && (n64 & (n64 - 1)) == 0;
+}
+
 bool wino4_eligible(const ConvParams &p) {
-  return !p.stem && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && p.Cin % W4BK == 0 && p.Cout % 64 == 0 &&
+  return !p.stem && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == p.dil && wino4_channels_ok(p.Cin, p.Cout) &&
          p.Ho == p.H && p.Wo == p.W;
 }
 
@@ -396,14 +411,41 @@ static long wino4_elem_blocks(long items) {
   return blocks < cap ? blocks : cap;
 }
 
+static int launch_wino4_slice(const ConvParams &p0, int Bg, int b0, const float *U, float *ws, hipStream_t st);
+
 int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_t st) {
   UOC_REQUIRE(wino4_eligible(p), "winograd F(4x4): layer not eligible");
-  UOC_REQUIRE(U && ws, "winograd F(4x4): null weight/workspace pointer");
-  const Wino4Geom geo = make_geom4(p.B, p.H, p.W, p.dil);
+  UOC_REQUIRE(U && ws && p.in && p.out, "winograd F(4x4): null tensor/weight/workspace pointer");
   const int planes = 36 * p.G;
-  UOC_REQUIRE((size_t)planes * geo.NT * (p.Cin > p.Cout ? p.Cin : p.Cout) * 4 < (1ull << 32) &&
-                  (size_t)planes * p.Cout * p.Cin * 4 < (1ull << 32),
-              "winograd F(4x4): frequency planes exceed the 4 GB a 32-bit buffer offset addresses (batch too large)");
+  UOC_REQUIRE((size_t)planes * p.Cout * p.Cin * 4 < (1ull << 32), "winograd F(4x4): weight planes exceed 4 GB");
+  // The plane GEMM addresses V and M with 32-bit buffer offsets: a batch whose frequency planes exceed 4 GB is run as
+  // several launches over slices of the batch (same tiles, same arithmetic: a tile never spans two images).
+  const size_t per_image = (size_t)planes * make_geom4(1, p.H, p.W, p.dil).NT * (p.Cin > p.Cout ? p.Cin : p.Cout) * 4;
+  UOC_REQUIRE(per_image < (1ull << 32), "winograd F(4x4): one image's frequency planes exceed 4 GB");
+  static EnvInt limit_mb("UOC_WINO4_MAX_MB", 0);   // dev / tests: a smaller limit, to exercise the split on small batches
+  const size_t limit = limit_mb.get() > 0 && ((size_t)limit_mb.get() << 20) > per_image ? (size_t)limit_mb.get() << 20 : (1ull << 32) - 1;
+  const int bmax = (int)(limit / per_image);
+  if (p.B > bmax) {
+    for (int b0 = 0; b0 < p.B; b0 += bmax) {
+      ConvParams q = p;
+      q.B = p.B - b0 < bmax ? p.B - b0 : bmax;
+      if (int rc = launch_wino4_slice(q, p.B, b0, U, ws, st)) return rc;
+    }
+    return UOC_OK;
+  }
+  return launch_wino4_slice(p, p.B, 0, U, ws, st);
+}
+
+// images b0 .. b0 + p.B - 1 of a batch of Bg (activation tensors [g][Bg][H][W][C])
+static int launch_wino4_slice(const ConvParams &p0, int Bg, int b0, const float *U, float *ws, hipStream_t st) {
+  ConvParams p = p0;
+  const size_t img_in = (size_t)p.H * p.W * p.Cin, img_out = (size_t)p.H * p.W * p.Cout;
+  p.in += (size_t)b0 * img_in;
+  p.out += (size_t)b0 * img_out;
+  if (p.res) p.res += (size_t)b0 * img_out;
+  Wino4Geom geo = make_geom4(p.B, p.H, p.W, p.dil);
+  geo.Bg = Bg;
+  const int planes = 36 * p.G;
   float *V = ws, *Mw = ws + (size_t)planes * geo.NT * p.Cin;
   const double Mpix = (double)p.B * p.H * p.W;
   const ProfTag tag = {{geo.NT, p.Cin, p.Cout, p.dil}};
@@ -426,8 +468,8 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
       hipLaunchKernelGGL(wino4_input_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
     UOC_LAUNCH_CHECK();
   }
-  int gemm_mode = 2;   // 2 = the persistent plane-GEMM kernel; 1 = one direct 1x1 "convolution" over 36*G groups (A/B, dev)
-  if (const char *e = getenv("UOC_WINO4_GEMM")) gemm_mode = atoi(e);
+  static EnvInt gemm_env("UOC_WINO4_GEMM", 2);   // 2 = the persistent plane-GEMM kernel; 1 = one direct 1x1 "convolution" over 36*G groups (A/B, dev)
+  const int gemm_mode = gemm_env.get() == 1 ? 1 : 2;
   // algorithmic flops = the direct 3x3 convolution's; the matrix pipe executes 36/144 of them
   // (+ the padding of partial tiles); bytes: V and U read once, M written once
   const double gflops = 2.0 * Mpix * p.Cout * p.Cin * 9.0 * p.G;

@@ -18,6 +18,7 @@ namespace uoc {
 
 struct Wino4Geom {
   int B, H, W, d, TH, TW, NT;  // TH x TW tiles of 4x4 outputs per (image, dilation phase); NT = B*d*d*TH*TW
+  int Bg;                      // images per group in the activation tensors [g][Bg][H][W][C] (>= B: a launch may cover a slice of the batch)
 };
 
 __host__ __device__ inline Wino4Geom make_geom4(int B, int H, int W, int d) {
@@ -29,6 +30,7 @@ __host__ __device__ inline Wino4Geom make_geom4(int B, int H, int W, int d) {
   g.TH = ((H + d - 1) / d + 3) / 4;
   g.TW = ((W + d - 1) / d + 3) / 4;
   g.NT = B * d * d * g.TH * g.TW;
+  g.Bg = B;
   return g;
 }
 
@@ -136,7 +138,7 @@ __host__ __device__ inline void wino4_input_body(const float *in, float *V, cons
   typedef typename W4Vec<VEC>::type T;
   int b, oy, ox;
   wino4_decode(tau, geo, b, oy, ox);
-  const float *src = in + (((size_t)g * geo.B + b) * geo.H * geo.W) * C + VEC * cv;
+  const float *src = in + (((size_t)g * geo.Bg + b) * geo.H * geo.W) * C + VEC * cv;
   T t[6][6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -185,8 +187,12 @@ __host__ __device__ inline void wino4_output_body(const float *M, const float *b
   }
   int b, oy, ox;
   wino4_decode(tau, geo, b, oy, ox);
-  const size_t gsz = (size_t)geo.B * geo.H * geo.W * Cout;
-  const T bv = *reinterpret_cast<const T *>(bias + (size_t)g * Cout + VEC * cv);
+  const size_t gsz = (size_t)geo.Bg * geo.H * geo.W * Cout;
+  T bv;
+  if (bias)
+    bv = *reinterpret_cast<const T *>(bias + (size_t)g * Cout + VEC * cv);
+  else
+    w4_zero(bv);   // a null bias is zero, as in the direct kernels
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     T yv[4];

@@ -34,7 +34,7 @@ def frame_rng_seed(frame_index: int) -> int:
 def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height: int, width: int,
                 device: torch.device, rank: int = 0, world: int = 1, gather: bool = True,
                 force_collective: bool = False, inflight: Optional[int] = None,
-                timing: Optional[dict] = None) -> Optional[torch.Tensor]:
+                timing: Optional[dict] = None, block_range: Optional[tuple] = None) -> Optional[torch.Tensor]:
     """Runs frame_fn(global_index) -> [H,W] integer label map (on `device`) for this rank's block
     and all-gathers the uint8 blocks.  Returns [num_frames, H, W] uint8 on `device` (every rank),
     or only the local block when gather=False / world == 1.
@@ -47,12 +47,19 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     many frames are kept in flight on this GPU, each on its own stream (_run_block_pipelined); 1 = one frame at a
     time on the current stream.  The label maps are the same either way.
 
+    `block_range` = (lo, hi): run exactly the global frames [lo, hi) on this process (world must be 1, no gather) — what a
+    rank of a larger job does for its block, without emulating a rank / world pair (tests that walk a long frame list in
+    resident chunks).
+
     `timing`: if given, receives this rank's 'compute_s' (its frame block, device-synchronised) and 'gather_s' (error-flag
     all-reduce + all_gather) — the per-rank breakdown bench.py prints for multi-GPU runs."""
     import time
     t_start = time.perf_counter()
     per = (num_frames + world - 1) // world
-    lo, hi = shard_range(num_frames, rank, world)
+    lo, hi = shard_range(num_frames, rank, world) if block_range is None else block_range
+    if block_range is not None:
+        assert world == 1 and not gather and 0 <= lo <= hi, "block_range: an explicit global frame block, single rank"
+        per = hi - lo
     block = torch.zeros((per, height, width), dtype=torch.uint8, device=device)
     collective = gather and (world > 1 or force_collective)
     error = None
