@@ -240,3 +240,28 @@ def test_winograd4_edge_cases(device):
     assert torch.equal(whole, sliced)
     ref = F.relu(torch.stack([F.conv2d(x[i], w[i], b[i], padding=2, dilation=2) for i in range(2)]) + res)
     assert (whole - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("shape", [(1, 480, 640), (2, 240, 320), (5, 224, 224), (1, 72, 104), (3, 61, 83)])
+def test_fused_transforms_are_bit_identical(device, shape):
+    """Round 4: inside a chain of F(4x4) layers the output transform of one layer and the input
+    transform of the next can run as ONE kernel through LDS (csrc/wino4.hip, wino4_mid_kernel; the intermediate NHWC
+    tensor of a BasicBlock is never written).  Built, bit-identical, and measured SLOWER end to end
+    (profiles/r04_ab_fused_transforms.md), so it is opt-in (UOC_WINO4_FUSE=1).  It calls the arithmetic of the separate
+    kernels (wino4_math.h), so the embeddings must not change by a bit, ragged sizes included."""
+    B, H, W = shape
+    net, _ = _net(3, device)
+    g = torch.Generator().manual_seed(H * W + B)
+    img = torch.randn(B, 3, H, W, generator=g).to(device)
+    xyz = torch.randn(B, 3, H, W, generator=g).to(device)
+    L = _native.lib()
+    separate = net(img, None, xyz).clone()
+    os.environ["UOC_WINO4_FUSE"] = "1"
+    L.uoc_reload_env()
+    try:
+        fused = net(img, None, xyz).clone()
+    finally:
+        os.environ.pop("UOC_WINO4_FUSE", None)
+        L.uoc_reload_env()
+    assert torch.equal(fused, separate)
+    assert torch.isfinite(fused).all()

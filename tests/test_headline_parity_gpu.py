@@ -42,6 +42,8 @@ DECOMPOSED_FRAMES = int(os.environ.get("UOC_PARITY_FRAMES", "24"))     # frames 
 # measured bounds of the end-to-end comparison (profiles/r03_parity_histogram.json, 1 024 frames: 958 identical up to
 # permutation, 39 x 1, 12 x 2, 7 x 3, 3 x 4, 3 x 5 pixels, one frame 17 and one 24 pixels of 307 200 — and on those worst
 # frames the integer path is bit-exact given the oracle's embeddings, profiles/r03_parity_decomposed_outlier_frames.json)
+EMBED_EPS = 2.5e-6                     # per-component embedding error of the perturbed oracle runs = the measured HIP-vs-oracle maximum ((a): 2.5e-6; bar 1e-3)
+MAX_FLAGGED_FRAMES = 12                # frames (of 1 024) that may need the perturbation analysis (~30 s of oracle each); more = a regression
 E2E_MIN_EXACT_FRACTION = 0.90          # secondary alarm only: share of frames identical up to a permutation (measured 0.936)
 
 
@@ -207,7 +209,7 @@ def test_end_to_end_margin_bounded(device, nets):
     n = min(n, int(os.environ.get("UOC_PARITY_E2E_FRAMES", "1024")))
     assert n >= 8, "tests/golden/bench_oracle/ or bench_margins/ is missing"
     CH = 64                                   # frames resident at a time (7.4 MB each)
-    hist, per_frame, pixels, beyond, worst_margin = {}, [], [], [], 0.0
+    hist, per_frame, pixels, beyond, worst_margin, flagged, bifurcated = {}, [], [], [], 0.0, [], []
     workers = max(1, min(32, len(os.sched_getaffinity(0)) - 2))
     with ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as pool:     # spawn: this process holds a HIP context
         chunks = [(lo, min(n, lo + CH)) for lo in range(0, n, CH)]
@@ -229,36 +231,39 @@ def test_end_to_end_margin_bounded(device, nets):
                 m = _lookup(mar[g]["idxF"], mar[g]["valF"], bad)
                 over = m > M.TAU
                 if over.any():
-                    # the one legitimate cascade: a stage-1 near-tie pixel that sits on a label's bounding box moves the
-                    # padded ROI (test_dataset.py:78-90), the crop is resampled on another grid and stage 2 starts from
-                    # different inputs.  Accept it only if it is exactly that.
-                    np.random.seed(runner.frame_rng_seed(g))
-                    out1, _ = TD.test_sample(dict(image_color=samples[g - lo]["image_color"].cpu(), depth=samples[g - lo]["depth"].cpu()), net, None)
-                    bad1 = _mismatching_pixels(out1[0].numpy(), fix[g][0])
-                    m1 = _lookup(mar[g]["idx1"], mar[g]["val1"], bad1)
-                    _, boxes = GO.roi_boxes(out1[0])
-                    moved = [k for k in range(len(mar[g]["rois"])) if k >= len(boxes) or not np.array_equal(boxes[k].numpy(), mar[g]["rois"][k])]
-                    ok = len(bad1) > 0 and bool((m1 <= M.TAU).all()) and len(boxes) == len(mar[g]["rois"]) and len(moved) > 0
-                    if ok:      # every beyond-margin pixel must lie inside a moved ROI window (old or new box)
-                        yy, xx = np.divmod(bad[over], W)
-                        inside = np.zeros(len(yy), bool)
-                        for k in moved:
-                            for x0, y0, x1, y1 in (mar[g]["rois"][k], boxes[k].numpy()):
-                                inside |= (xx >= x0) & (xx <= x1) & (yy >= y0) & (yy <= y1)
-                        ok = bool(inside.all())
-                    cls = "roi_moved_by_stage1_near_tie" if ok else "BEYOND_MARGIN"
-                    if not ok:
-                        beyond.append({"frame": g, "pixels": int(over.sum()), "stage1_mismatches": int(len(bad1)),
-                                       "stage1_margins": [float(v) for v in m1[:16]]})
-                else:
-                    cls = "near_tie"
-                    worst_margin = max(worst_margin, float(m.max()))
+                    flagged.append((g, bad, m))
+                    continue
+                worst_margin = max(worst_margin, float(m.max()))
                 for p, v in zip(bad.tolist(), m.tolist()):
-                    pixels.append({"frame": g, "y": p // W, "x": p % W, "margin": (round(v, 9) if np.isfinite(v) else None), "class": cls})
+                    pixels.append({"frame": g, "y": p // W, "x": p % W, "margin": round(v, 9), "class": "near_tie"})
+    # Frames with a pixel beyond the margin: either a regression, or a seed between two modes (oracle/margins.py: the
+    # margin bounds the assignment GIVEN the seeds; at such a seed the oracle's own result flips with the last bit of a
+    # sum — bench frame 246: 1 vs 4 torch threads).  Ask the oracle: its whole path again with the embeddings perturbed by
+    # the measured embedding error (twice, seeded) and once on the HIP networks' embeddings; every mismatching pixel must
+    # be one whose label changes in at least one of those runs, or a near-tie of this host's oracle run, or a pixel on
+    # which this host's oracle run itself differs from the committed one.
+    assert len(flagged) <= MAX_FLAGGED_FRAMES, [f[0] for f in flagged]
+    cpu_net = lambda image, label, depth: BO.segnet_forward(sd, image, depth)
+    hip1 = lambda image, label, depth: net(image.to(device), None, depth.to(device)).cpu()
+    hip2 = lambda image, label, depth: net_crop(image.to(device), None, depth.to(device)).cpu()
+    for g, bad, m in flagged:
+        img, dep = _bench_frame(g)
+        changed, base, info = M.unresolved_pixels(img, dep, cpu_net, runner.frame_rng_seed(g), EMBED_EPS, runs=2,
+                                                  extra_networks=[(hip1, hip2)])
+        here_vs_there = M.label_changes(fix[g][1], base)
+        ok = np.isin(bad, changed) | np.isin(bad, here_vs_there) | (m <= M.TAU) | (info["marginF"].reshape(-1)[bad] <= M.TAU)
+        for p, v, good in zip(bad.tolist(), m.tolist(), ok.tolist()):
+            pixels.append({"frame": g, "y": p // W, "x": p % W, "margin": (round(v, 9) if np.isfinite(v) else None),
+                           "class": "unresolved_by_the_oracle" if good else "BEYOND_MARGIN"})
+        bifurcated.append({"frame": g, "mismatching_pixels": int(len(bad)), "beyond_tau": int((m > M.TAU).sum()),
+                           "pixels_the_oracle_flips_under_perturbation": int(len(changed)),
+                           "oracle_here_vs_fixture_pixels": int(len(here_vs_there)), "unexplained": int((~ok).sum())})
+        if not ok.all():
+            beyond.append(bifurcated[-1])
     exact = hist.get(0, 0) / n
     out = {"frames": n, "tau": M.TAU, "mismatching_pixels": len(pixels), "pixels_total": n * H * W,
-           "mismatches_beyond_margin": int(sum(b["pixels"] for b in beyond)), "largest_margin_of_a_mismatch": worst_margin,
-           "frames_with_a_moved_roi": sorted({p["frame"] for p in pixels if p["class"] == "roi_moved_by_stage1_near_tie"}),
+           "mismatches_unexplained": int(sum(b["unexplained"] for b in beyond)), "largest_margin_of_a_near_tie_mismatch": worst_margin,
+           "embedding_perturbation": EMBED_EPS, "frames_with_an_unresolved_seed": bifurcated,
            "exact_fraction": exact, "histogram_mismatched_pixels": {str(k): hist[k] for k in sorted(hist)},
            "beyond": beyond, "pixels": pixels, "per_frame": per_frame}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -278,7 +283,8 @@ def test_tau_is_the_measured_perturbation(device, nets):
     next to the HIP kernels on the first AMP_FRAMES bench frames.  Reports, for stage 1 and for the crops,
       dx            max L2 error of a pixel's embedding (HIP network vs oracle network, same inputs)
       dz_kernel     max L2 distance of a converged seed, HIP hill climbing vs oracle, SAME (oracle) embeddings
-      dz            the same with the HIP embeddings: dx amplified by ten kappa = 20 iterations
+      dz            the same with the HIP embeddings: dx amplified by ten kappa = 20 iterations (99th percentile over the
+                    seeds; dz_max and the number of seeds beyond TAU next to it — seeds between two modes)
     and asserts dx + dz <= TAU.  Also checks the oracle run on THIS host against the committed near-tie sets."""
     from oracle import margins as M
     from unseenobjectclustering_amd.utils import mean_shift as MS
@@ -305,7 +311,11 @@ def test_tau_is_the_measured_perturbation(device, nets):
             dx = float((Xh.cpu() - Xo).norm(dim=-1).max())
             _, _, Zk, _ = MS.cluster_batch(Xo.to(device), first, 20.0, 100, 10, 0.04, return_parts=True)
             _, _, Zh, _ = MS.cluster_batch(Xh, first, 20.0, 100, 10, 0.04, return_parts=True)
-            row[tag] = {"dx": dx, "dz_kernel": float((Zk.cpu() - Zo).norm(dim=-1).max()), "dz": float((Zh.cpu() - Zo).norm(dim=-1).max())}
+            dzk, dzh = (Zk.cpu() - Zo).norm(dim=-1).reshape(-1), (Zh.cpu() - Zo).norm(dim=-1).reshape(-1)
+            # a seed between two modes has no bounded amplification (oracle/margins.py, bench frame 246): the bound is stated
+            # for the 99th percentile of the seeds, the rest is counted (and covered by (c)'s perturbation analysis)
+            row[tag] = {"dx": dx, "dz_kernel": float(dzk.quantile(0.99)), "dz": float(dzh.quantile(0.99)), "dz_max": float(dzh.max()),
+                        "seeds": int(dzh.numel()), "seeds_moved_more_than_tau": int((dzh > M.TAU).sum())}
             row[tag]["amplification"] = row[tag]["dz"] / max(dx, 1e-12)
         # the oracle on this host against the committed near-tie sets (made in the build container): same pixels below
         # TAU_STORE / 2 (the edge of the stored set may move by an ulp of the margin)

@@ -203,6 +203,7 @@ static Dims dims(int H, int W) {
 
 struct NetWs {
   float *in4, *stem, *stem_part, *buf[4], *fc, *wino;
+  size_t wino_half;   // F(4x4): floats per half of `wino` (V planes | M planes)
   size_t total;
 };
 static NetWs carve_net(void *base, int mode, int wino_f, int B, int H, int W) {
@@ -241,12 +242,13 @@ static NetWs carve_net(void *base, int mode, int wino_f, int B, int H, int W) {
     }
   }
   w.wino = take(wv);
+  w.wino_half = wv / 2;
   w.total = off;
   return w;
 }
 
-static int run_conv(int G, const ConvLayer &L, const float *in, const float *res, float *out, int B, int H, int W,
-                    int Ho, int Wo, hipStream_t st, float *wino_ws = nullptr) {
+static ConvParams conv_params(int G, const ConvLayer &L, const float *in, const float *res, float *out, int B, int H, int W,
+                              int Ho, int Wo) {
   ConvParams p;
   p.in = in;
   p.w = L.d_w;
@@ -267,6 +269,12 @@ static int run_conv(int G, const ConvLayer &L, const float *in, const float *res
   p.pad = L.pad;
   p.relu = L.relu;
   p.stem = L.stem ? 1 : 0;
+  return p;
+}
+
+static int run_conv(int G, const ConvLayer &L, const float *in, const float *res, float *out, int B, int H, int W,
+                    int Ho, int Wo, hipStream_t st, float *wino_ws = nullptr) {
+  const ConvParams p = conv_params(G, L, in, res, out, B, H, W, Ho, Wo);
   if (L.d_U4 && wino_ws && wino4_eligible(p)) return launch_wino4_conv(p, L.d_U4, wino_ws, st);
   if (L.d_U && wino_ws && wino_eligible(p)) return launch_wino_conv(p, L.d_U, wino_ws, st);
   return launch_conv(p, st);
@@ -370,22 +378,58 @@ int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, i
   }
   if (int rc = launch_maxpool3x3s2(w.stem, w.buf[0], G * B, d.H1, d.W1, 64, d.H2, d.W2, st)) return rc;
 
+  // Consecutive F(4x4) layers form a chain: the M planes of a layer stay "pending" until the next step decides how they
+  // are turned into activations — fused with the next layer's input transform (wino4_chain_mid: same geometry, the NHWC
+  // tensor is written only if somebody else reads it), or by the plain output transform.
+  float *Vp = w.wino, *Mp = w.wino ? w.wino + w.wino_half : nullptr;
+  bool pending = false;
+  ConvParams pend;
+  auto flush = [&]() -> int {   // the pending layer's output transform on its own
+    if (!pending) return UOC_OK;
+    pending = false;
+    return wino4_chain_output(pend, Mp, st);
+  };
+  // one convolution of the chain; `keep_y`: if it is fused INTO (its input is the pending layer's output), must that
+  // output also exist as an NHWC tensor (a residual or a 1x1 shortcut reads it)?
+  auto conv_step = [&](const ConvLayer &L, const float *in, const float *res, float *out, int h_, int w_, int ho_, int wo_,
+                       bool keep_y) -> int {
+    const ConvParams p = conv_params(G, L, in, res, out, B, h_, w_, ho_, wo_);
+    if (L.d_U4 && Vp && wino4_chain_ok(p)) {
+      if (pending && pend.out == in && wino4_can_fuse(pend, p)) {
+        if (int rc = wino4_chain_mid(pend, keep_y, Mp, Vp, st)) return rc;
+        pending = false;
+      } else {
+        if (int rc = flush()) return rc;
+        if (int rc = wino4_chain_input(p, Vp, st)) return rc;
+      }
+      if (int rc = wino4_chain_gemm(p, L.d_U4, Vp, Mp, st)) return rc;
+      pend = p;
+      pending = true;
+      return UOC_OK;
+    }
+    if (int rc = flush()) return rc;
+    return run_conv(G, L, in, res, out, B, h_, w_, ho_, wo_, st, w.wino);
+  };
   int cur = 0, h = d.H2, wd = d.W2;
   for (const Block &b : n->blocks) {
     const ConvLayer &c1 = n->layers[b.conv1], &c2 = n->layers[b.conv2];
     const int ho = (h - 1) / c1.stride + 1, wo = (wd - 1) / c1.stride + 1;
     float *x = w.buf[cur], *tmp = w.buf[(cur + 1) & 3], *sc = w.buf[(cur + 2) & 3], *y = w.buf[(cur + 3) & 3];
-    if (int rc = run_conv(G, c1, x, nullptr, tmp, B, h, wd, ho, wo, st, w.wino)) return rc;
+    // the block input x (= the previous block's output) is always needed as a tensor: residual or shortcut input
+    if (int rc = conv_step(c1, x, nullptr, tmp, h, wd, ho, wo, true)) return rc;
     const float *res = x;
     if (b.down >= 0) {
+      // the 1x1 shortcut reads x; x is complete by now (the fused step above wrote it, or flush() did)
       if (int rc = run_conv(G, n->layers[b.down], x, nullptr, sc, B, h, wd, ho, wo, st)) return rc;
       res = sc;
     }
-    if (int rc = run_conv(G, c2, tmp, res, y, B, ho, wo, ho, wo, st, w.wino)) return rc;
+    // conv1's output feeds conv2 only: when fused, the NHWC tensor `tmp` is never written
+    if (int rc = conv_step(c2, tmp, res, y, ho, wo, ho, wo, false)) return rc;
     cur = (cur + 3) & 3;
     h = ho;
     wd = wo;
   }
+  if (int rc = flush()) return rc;
   if (int rc = run_conv(G, n->layers[n->fc], w.buf[cur], nullptr, w.fc, B, h, wd, h, wd, st)) return rc;
   return launch_head(w.fc, G == 2 ? w.fc + (size_t)B * h * wd * 64 : nullptr, d_embed, B, h, wd, H, W,
                      n->mode == UOC_NET_RGBD_CAT, st);

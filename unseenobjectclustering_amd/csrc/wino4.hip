@@ -66,6 +66,91 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
   }
 }
 
+
+// ---- output transform of layer L fused with the input transform of layer L+1 (same geometry) --------------------------
+// Inside a chain of Winograd layers of one resolution and dilation the NHWC activation between two layers is only ever
+// read back as 6x6 patches.  One block owns one dilation-phase image of one (group, image) and CS channels: it turns the
+// phase image's M tiles into outputs (A^T M A + bias (+ residual), ReLU: wino4_math.h, the very functions of the two
+// separate kernels, so the results are bit-identical), keeps them in LDS with the one-pixel zero frame the next
+// convolution's padding asks for, and transforms the 6x6 patches straight into the next layer's V planes.  A phase image
+// has no neighbours (its halo is padding), so no tile is computed twice.  The activation itself is written to HBM only
+// when somebody else needs it (the next block's residual): per pair of layers 4.5 instead of 6.5-7.75 activation sizes
+// move.  Layout of the LDS image: [(4 TH + 2) rows][(4 TW + 2) columns][CS / 4] float4.
+template <int VEC>
+__global__ __launch_bounds__(VEC == 4 ? 256 : 512) void wino4_mid_kernel(const float *__restrict__ M, const float *__restrict__ bias,
+                                                        const float *__restrict__ res, float *__restrict__ yout,
+                                                        float *__restrict__ V, Wino4Geom geo, int G, int C, int relu, int CS,
+                                                        int sib, int units) {
+  typedef typename W4Vec<VEC>::type T;
+  extern __shared__ __attribute__((aligned(16))) float ysm_raw[];
+  T *ysm = reinterpret_cast<T *>(ysm_raw);
+  const int Q = CS / VEC, slices = C / CS;
+  const int Wl = 4 * geo.TW + 2, Hl = 4 * geo.TH + 2;
+  // blocks are dealt to the 8 XCDs round-robin; `sib` sibling slices share 128-byte lines of M and V, so they are
+  // mapped to consecutive blocks of ONE XCD (one L2 fetches the line once)
+  const int x8 = blockIdx.x & 7, j8 = blockIdx.x >> 3;
+  const int unit = ((j8 / sib) * 8 + x8) * sib + j8 % sib;
+  if (unit >= units) return;
+  const int slice = unit % slices;
+  int u = unit / slices;
+  const int px = u % geo.d;
+  u /= geo.d;
+  const int py = u % geo.d;
+  u /= geo.d;
+  const int b = u % geo.B, g = u / geo.B;
+  const int ntile = geo.TH * geo.TW, items = ntile * Q;
+  const int tile0 = ((b * geo.d + py) * geo.d + px) * ntile;
+  const size_t plane = (size_t)geo.NT * C;
+  const size_t gsz = (size_t)geo.Bg * geo.H * geo.W * C;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+
+  for (int i = tid; i < Hl * Wl * Q; i += nthr) w4_zero(ysm[i]);
+  __syncthreads();
+  for (int it = tid; it < items; it += nthr) {
+    const int cq = it % Q, t = it / Q, ty = t / geo.TW, tx = t - ty * geo.TW;
+    const int ch = slice * CS + VEC * cq;
+    const float *src = M + (size_t)g * 36 * plane + (size_t)(tile0 + t) * C + ch;
+    T m[36];
+#pragma unroll
+    for (int k = 0; k < 36; ++k) m[k] = *reinterpret_cast<const T *>(src + (size_t)k * plane);
+    T yv[4][4];
+    wino4_output_tile(m, yv);
+    T bv;
+    if (bias)
+      bv = *reinterpret_cast<const T *>(bias + (size_t)g * C + ch);
+    else
+      w4_zero(bv);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int y = py + (4 * ty + a) * geo.d;
+      if (y >= geo.H) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int x = px + (4 * tx + e) * geo.d;
+        if (x >= geo.W) continue;
+        const size_t o = (size_t)g * gsz + (((size_t)b * geo.H + y) * geo.W + x) * C + ch;
+        const T v = wino4_epilogue(yv[a][e], bv, res ? res + o : nullptr, relu);
+        ysm[((4 * ty + a + 1) * Wl + 4 * tx + e + 1) * Q + cq] = v;
+        if (yout) *reinterpret_cast<T *>(yout + o) = v;
+      }
+    }
+  }
+  __syncthreads();
+  for (int it = tid; it < items; it += nthr) {
+    const int cq = it % Q, t = it / Q, ty = t / geo.TW, tx = t - ty * geo.TW;
+    T d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) d[i][j] = ysm[((4 * ty + i) * Wl + 4 * tx + j) * Q + cq];
+    T v[36];
+    wino4_input_tile(d, v);
+    float *dst = V + (size_t)g * 36 * plane + (size_t)(tile0 + t) * C + slice * CS + VEC * cq;
+#pragma unroll
+    for (int k = 0; k < 36; ++k) *reinterpret_cast<T *>(dst + (size_t)k * plane) = v[k];
+  }
+}
+
 // ---- the batched GEMM over (group, frequency) planes -------------------------------------------------------------
 __device__ __forceinline__ f32x4 w4mfma(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -385,7 +470,7 @@ bool wino4_eligible(const ConvParams &p) {
 
 size_t wino4_ws_floats(int G, int B, int H, int W, int d, int Cin, int Cout) {
   const Wino4Geom geo = make_geom4(B, H, W, d);
-  return (size_t)G * 36 * geo.NT * ((size_t)Cin + Cout);
+  return (size_t)G * 36 * geo.NT * 2 * (size_t)(Cin > Cout ? Cin : Cout);   // two halves: V planes, M planes (chains of layers use them as such)
 }
 
 int launch_wino4_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st) {
@@ -436,38 +521,33 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
   return launch_wino4_slice(p, p.B, 0, U, ws, st);
 }
 
-// images b0 .. b0 + p.B - 1 of a batch of Bg (activation tensors [g][Bg][H][W][C])
-static int launch_wino4_slice(const ConvParams &p0, int Bg, int b0, const float *U, float *ws, hipStream_t st) {
-  ConvParams p = p0;
-  const size_t img_in = (size_t)p.H * p.W * p.Cin, img_out = (size_t)p.H * p.W * p.Cout;
-  p.in += (size_t)b0 * img_in;
-  p.out += (size_t)b0 * img_out;
-  if (p.res) p.res += (size_t)b0 * img_out;
-  Wino4Geom geo = make_geom4(p.B, p.H, p.W, p.dil);
-  geo.Bg = Bg;
-  const int planes = 36 * p.G;
-  float *V = ws, *Mw = ws + (size_t)planes * geo.NT * p.Cin;
+// ---- the three stages of one layer, and the fused stage between two layers --------------------------------------------
+static int w4_vec() {   // channels per thread of the two elementwise kernels (UOC_W4_VEC, A/B): 4 (float4) moves the most bytes per instruction
+  static EnvInt e("UOC_W4_VEC", 4);
+  const int v = e.get();
+  return v == 1 || v == 2 ? v : 4;
+}
+
+static int w4_stage_input(const ConvParams &p, const Wino4Geom &geo, float *V, hipStream_t st) {
   const double Mpix = (double)p.B * p.H * p.W;
   const ProfTag tag = {{geo.NT, p.Cin, p.Cout, p.dil}};
-  // channels per thread of the two elementwise kernels: 4 (float4) moves the most bytes per instruction; 1 or 2 need a
-  // quarter / half of the registers (UOC_W4_VEC, A/B)
-  static int vec = 0;
-  if (!vec) {
-    const char *e = getenv("UOC_W4_VEC");
-    vec = e ? atoi(e) : 4;
-    if (vec != 1 && vec != 2) vec = 4;
-  }
-  {
-    ProfScope prof(KC_WINO4_INPUT, st, 0.0, 4.0 * p.G * (Mpix * p.Cin + 36.0 * geo.NT * p.Cin), tag);
-    const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cin / vec));
-    if (vec == 1)
-      hipLaunchKernelGGL(wino4_input_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
-    else if (vec == 2)
-      hipLaunchKernelGGL(wino4_input_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
-    else
-      hipLaunchKernelGGL(wino4_input_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
-    UOC_LAUNCH_CHECK();
-  }
+  const int vec = w4_vec();
+  ProfScope prof(KC_WINO4_INPUT, st, 0.0, 4.0 * p.G * (Mpix * p.Cin + 36.0 * geo.NT * p.Cin), tag);
+  const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cin / vec));
+  if (vec == 1)
+    hipLaunchKernelGGL(wino4_input_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
+  else if (vec == 2)
+    hipLaunchKernelGGL(wino4_input_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
+  else
+    hipLaunchKernelGGL(wino4_input_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+static int w4_stage_gemm(const ConvParams &p, const Wino4Geom &geo, const float *U, float *V, float *Mw, hipStream_t st) {
+  const int planes = 36 * p.G;
+  const double Mpix = (double)p.B * p.H * p.W;
+  const ProfTag tag = {{geo.NT, p.Cin, p.Cout, p.dil}};
   static EnvInt gemm_env("UOC_WINO4_GEMM", 2);   // 2 = the persistent plane-GEMM kernel; 1 = one direct 1x1 "convolution" over 36*G groups (A/B, dev)
   const int gemm_mode = gemm_env.get() == 1 ? 1 : 2;
   // algorithmic flops = the direct 3x3 convolution's; the matrix pipe executes 36/144 of them
@@ -499,22 +579,121 @@ static int launch_wino4_slice(const ConvParams &p0, int Bg, int b0, const float 
     q.prof_kc = KC_WINO4_GEMM;
     q.prof_flops = gflops;
     q.prof_tag[0] = geo.NT, q.prof_tag[1] = p.Cin, q.prof_tag[2] = p.Cout, q.prof_tag[3] = p.dil;
-    if (int rc = launch_conv(q, st)) return rc;
-  } else {
-    ProfScope prof(KC_WINO4_GEMM, st, gflops, gbytes, tag);
-    if (int rc = launch_wino4_gemm(V, U, Mw, geo.NT, p.Cin, p.Cout, planes, st)) return rc;
+    return launch_conv(q, st);
   }
-  {
-    ProfScope prof(KC_WINO4_OUTPUT, st, 0.0, 4.0 * p.G * (36.0 * geo.NT * p.Cout + Mpix * p.Cout * (p.res ? 2 : 1)), tag);
-    const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cout / vec));
-    if (vec == 1)
-      hipLaunchKernelGGL(wino4_output_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
-    else if (vec == 2)
-      hipLaunchKernelGGL(wino4_output_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
-    else
-      hipLaunchKernelGGL(wino4_output_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
-    UOC_LAUNCH_CHECK();
+  ProfScope prof(KC_WINO4_GEMM, st, gflops, gbytes, tag);
+  return launch_wino4_gemm(V, U, Mw, geo.NT, p.Cin, p.Cout, planes, st);
+}
+
+static int w4_stage_output(const ConvParams &p, const Wino4Geom &geo, const float *Mw, hipStream_t st) {
+  const double Mpix = (double)p.B * p.H * p.W;
+  const ProfTag tag = {{geo.NT, p.Cin, p.Cout, p.dil}};
+  const int vec = w4_vec();
+  ProfScope prof(KC_WINO4_OUTPUT, st, 0.0, 4.0 * p.G * (36.0 * geo.NT * p.Cout + Mpix * p.Cout * (p.res ? 2 : 1)), tag);
+  const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cout / vec));
+  if (vec == 1)
+    hipLaunchKernelGGL(wino4_output_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
+  else if (vec == 2)
+    hipLaunchKernelGGL(wino4_output_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
+  else
+    hipLaunchKernelGGL(wino4_output_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+// images b0 .. b0 + p.B - 1 of a batch of Bg (activation tensors [g][Bg][H][W][C])
+static int launch_wino4_slice(const ConvParams &p0, int Bg, int b0, const float *U, float *ws, hipStream_t st) {
+  ConvParams p = p0;
+  const size_t img_in = (size_t)p.H * p.W * p.Cin, img_out = (size_t)p.H * p.W * p.Cout;
+  p.in += (size_t)b0 * img_in;
+  p.out += (size_t)b0 * img_out;
+  if (p.res) p.res += (size_t)b0 * img_out;
+  Wino4Geom geo = make_geom4(p.B, p.H, p.W, p.dil);
+  geo.Bg = Bg;
+  float *V = ws, *Mw = ws + (size_t)36 * p.G * geo.NT * p.Cin;
+  if (int rc = w4_stage_input(p, geo, V, st)) return rc;
+  if (int rc = w4_stage_gemm(p, geo, U, V, Mw, st)) return rc;
+  return w4_stage_output(p, geo, Mw, st);
+}
+
+// ---- chains of layers (csrc/net.hip): V and M planes in caller-owned halves of the scratch; between two layers of one
+// geometry the fused kernel replaces output transform + input transform -------------------------------------------------
+// channels per block of the fused kernel: the largest slice whose LDS image (with its zero frame) fits 60 KB, so that two
+// blocks share a CU; 0 = the phase image is too large (stage-1 layer2: 62 x 82 pixels), the caller runs the two kernels
+static int w4_mid_vec() {   // channels per thread of the fused kernel: 2 (float2: 167 VGPRs, three waves per SIMD) or 4 (280 VGPRs: one wave)
+  static EnvInt e("UOC_W4_MID_VEC", 2);
+  return e.get() == 4 ? 4 : 2;
+}
+
+static int w4_mid_slice(const Wino4Geom &geo, int C) {
+  // OFF by default: measured slower end to end (profiles/r04_ab_fused_transforms.md) — the fused kernel needs ~50 KB of LDS
+  // per block and so cannot share a CU with another stream's plane GEMM, which the LDS-free separate kernels do.
+  static EnvInt on("UOC_WINO4_FUSE", 0);
+  if (on.get() == 0) return 0;
+  const int vec = w4_mid_vec(), max_threads = vec == 4 ? 256 : 512;
+  const long px = (long)(4 * geo.TH + 2) * (4 * geo.TW + 2), tiles = (long)geo.TH * geo.TW;
+  // one thread per (tile, VEC channels).  Measured (profiles/r04_ab_fused_transforms.md): the fused kernel only beats the
+  // two separate ones when a block's rows are whole 128-byte lines (>= 32 channels); the phase images of stage-1 layer3
+  // (30 x 40) and of the crops' layer2 (28 x 28) only fit LDS with 8 channels and lose.  Largest slice with at most 256
+  // items (one pass of a 4-wave block) and three blocks per CU (53 KB of LDS each); else the smallest eligible one.
+  static EnvInt min_cs("UOC_W4_MID_MIN_CS", 32);
+  int best = 0;
+  for (int cs = 8; cs <= 128; cs <<= 1) {
+    if (C % cs || px * cs * 4 > 53 * 1024) break;
+    if (cs < min_cs.get()) continue;
+    const long items = tiles * (cs / vec);
+    if (items <= 256 || (best == 0 && items <= max_threads)) best = cs;
   }
+  return best;
+}
+
+bool wino4_chain_ok(const ConvParams &p) {   // no batch split needed (32-bit plane offsets) and eligible
+  if (!wino4_eligible(p)) return false;
+  const Wino4Geom geo = make_geom4(p.B, p.H, p.W, p.dil);
+  return (size_t)36 * p.G * geo.NT * (p.Cin > p.Cout ? p.Cin : p.Cout) * 4 < (1ull << 32) &&
+         (size_t)36 * p.G * p.Cout * p.Cin * 4 < (1ull << 32);
+}
+
+bool wino4_can_fuse(const ConvParams &prev, const ConvParams &next) {
+  return prev.G == next.G && prev.B == next.B && prev.H == next.H && prev.W == next.W && prev.dil == next.dil &&
+         prev.Cout == next.Cin && w4_mid_slice(make_geom4(prev.B, prev.H, prev.W, prev.dil), prev.Cout) > 0;
+}
+
+int wino4_chain_input(const ConvParams &p, float *V, hipStream_t st) {
+  return w4_stage_input(p, make_geom4(p.B, p.H, p.W, p.dil), V, st);
+}
+int wino4_chain_gemm(const ConvParams &p, const float *U, float *V, float *Mw, hipStream_t st) {
+  return w4_stage_gemm(p, make_geom4(p.B, p.H, p.W, p.dil), U, V, Mw, st);
+}
+int wino4_chain_output(const ConvParams &p, const float *Mw, hipStream_t st) {
+  return w4_stage_output(p, make_geom4(p.B, p.H, p.W, p.dil), Mw, st);
+}
+
+// prev's output transform (bias, residual, ReLU; its NHWC tensor prev.out is written only if write_y) + the next layer's
+// input transform: Mw (prev's M planes) -> V (the next layer's V planes)
+int wino4_chain_mid(const ConvParams &prev, bool write_y, const float *Mw, float *V, hipStream_t st) {
+  const Wino4Geom geo = make_geom4(prev.B, prev.H, prev.W, prev.dil);
+  const int C = prev.Cout, cs = w4_mid_slice(geo, C);
+  UOC_REQUIRE(cs > 0, "winograd F(4x4): layers cannot be fused");
+  const int sib = cs < 32 ? 32 / cs : 1;
+  const int units = prev.G * prev.B * prev.dil * prev.dil * (C / cs);
+  const int grid = (units + 8 * sib - 1) / (8 * sib) * (8 * sib);
+  const int vec = w4_mid_vec();
+  const int items = geo.TH * geo.TW * (cs / vec);
+  int threads = (items + 63) / 64 * 64;
+  if (threads > (vec == 4 ? 256 : 512)) threads = vec == 4 ? 256 : 512;
+  const size_t lds = (size_t)(4 * geo.TH + 2) * (4 * geo.TW + 2) * cs * 4;
+  const double Mpix = (double)prev.B * prev.H * prev.W;
+  const ProfTag tag = {{geo.NT, C, C, prev.dil}};
+  ProfScope prof(KC_WINO4_MID, st, 0.0,
+                 4.0 * prev.G * (2.0 * 36.0 * geo.NT * C + Mpix * C * ((prev.res ? 1 : 0) + (write_y ? 1 : 0))), tag);
+  if (vec == 4)
+    hipLaunchKernelGGL(wino4_mid_kernel<4>, dim3((unsigned)grid), dim3(threads), lds, st, Mw, prev.bias, prev.res,
+                       write_y ? prev.out : nullptr, V, geo, prev.G, C, prev.relu, cs, sib, units);
+  else
+    hipLaunchKernelGGL(wino4_mid_kernel<2>, dim3((unsigned)grid), dim3(threads), lds, st, Mw, prev.bias, prev.res,
+                       write_y ? prev.out : nullptr, V, geo, prev.G, C, prev.relu, cs, sib, units);
+  UOC_LAUNCH_CHECK();
   return UOC_OK;
 }
 
