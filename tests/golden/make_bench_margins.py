@@ -61,8 +61,9 @@ def main():
         sl = info["slack"]
         slack.append([sl.get("seed_cc_stage1", np.inf), sl.get("depth_filter", np.inf), sl.get("seed_cc_crops", np.inf), sl.get("overlap", np.inf)])
         print(f"frame {g}: near-tie pixels {len(i1)} / {len(iF)}, differs from bench_oracle {differs[-1]}, {time.time() - t0:.0f}s", flush=True)
-    os.makedirs(os.path.join(ROOT, "tests", "golden", "bench_margins"), exist_ok=True)
-    path = os.path.join(ROOT, "tests", "golden", "bench_margins", f"frames_{lo:04d}_{hi:04d}.npz")
+    outdir = os.environ.get("UOC_MARGINS_OUT") or os.path.join(ROOT, "tests", "golden", "bench_margins")
+    os.makedirs(outdir, exist_ok=True)
+    path = os.path.join(outdir, f"frames_{lo:04d}_{hi:04d}.npz")
     np.savez_compressed(path, first=np.int64(lo), count=np.int64(hi - lo), tau_store=np.float32(M.TAU_STORE),
                         slack=np.asarray(slack, np.float32), differs_from_bench_oracle=np.asarray(differs, np.int32),
                         **{k: (np.concatenate(v) if v else np.zeros(0)) for k, v in acc.items()},

@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _bench(tmp_path, tag, force):
+def _bench(tmp_path, tag, force, steps=4):
     dump = os.path.join(str(tmp_path), tag + ".npy")
     env = dict(os.environ, UOC_BENCH_DUMP=dump, MASTER_PORT="29541")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
@@ -22,12 +22,12 @@ def _bench(tmp_path, tag, force):
         env["UOC_BENCH_FORCE_DIST"] = "1"
     else:
         env.pop("UOC_BENCH_FORCE_DIST", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", str(steps), "--warmup", "1",
                         "--cpu-frames", "0", "--profile-steps", "0", "--sustained-seconds", "0"], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(line) == 1
+    assert len(line) == 1 and len(line[0]) < 3000
     return json.loads(line[0]), np.load(dump)
 
 
@@ -41,3 +41,20 @@ def test_forced_collective_block_equals_plain_block(tmp_path, device):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump({"plain_fps": plain["value"], "forced_collective_fps": coll["value"]},
               open(os.path.join(ROOT, "gpurun_out", "forced_dist.json"), "w"))
+
+
+def test_a_rank_sized_block_through_the_collective(tmp_path, device):
+    """BASELINE configs[4]: one rank of the 8-GPU job holds 1024 / 8 = 128 frames = a 39 MB uint8 label-map block.  The
+    REAL frame function over 128 frames on this GPU with the nccl process group forced on (world size 1): the error-flag
+    all_reduce + all_gather_into_tensor of that block is timed (`gather_s` of the rank, on the compact line too) and the
+    line stays under the driver's tail."""
+    coll, maps = _bench(tmp_path, "rank_block", True, steps=128)
+    assert maps.shape == (128, 480, 640) and int(maps.max()) >= 5
+    assert coll["config"]["collective"] is True and coll["config"]["total_frames"] == 128
+    r = coll["per_rank"][0]
+    assert r["frames"] == 128 and r["gather_s"] >= 0.0 and r["compute_s"] > 0.1
+    assert r["gather_s"] < 0.25 * r["compute_s"], "the gather of one rank's block must stay a small part of the job"
+    rec = {"frames": 128, "block_bytes": int(maps.nbytes), "compute_s": r["compute_s"], "gather_s": r["gather_s"],
+           "frames_per_s": coll["value"], "world": 1, "backend": "nccl (RCCL), forced on one GPU"}
+    json.dump(rec, open(os.path.join(ROOT, "gpurun_out", "forced_dist_rank_block.json"), "w"))
+    print(json.dumps(rec))

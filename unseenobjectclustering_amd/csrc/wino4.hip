@@ -165,6 +165,18 @@ __device__ __forceinline__ f32x4 w4mfma(float a, float b, f32x4 c) {
 // Work items are ordered (plane, m-tile, n-tile).  Each XCD takes a contiguous eighth of the list (so that the rows of
 // one plane are pulled into ONE L2) and deals its items round-robin to its blocks: at any time the blocks of an XCD
 // work on neighbouring items = the same one or two planes.
+// -DUOC_W4_ABLATE=n (dev builds only, scripts/w4_ablate.sh; the results are WRONG, only the time means something): 1 = no
+// barriers, 2 = no vmcnt waits, 4 = no LDS-DMA issue (profiles/r04_pmc_mfma.md).  (Dropping the epilogue stores is not an
+// ablation: the compiler then removes the MFMAs.)
+#ifndef UOC_W4_ABLATE
+#define UOC_W4_ABLATE 0
+#endif
+#define W4_BARRIER() do { if (UOC_W4_ABLATE != 1) __builtin_amdgcn_s_barrier(); } while (0)
+template <int N>
+__device__ __forceinline__ void w4_wait_vmcnt() {
+  if (UOC_W4_ABLATE != 2) wait_vmcnt<N>();
+}
+
 template <int BM, int BN>
 __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
                                                          float *__restrict__ Mo, int NT, int Cin, int Cout, int planes,
@@ -245,6 +257,7 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
   {                                                                                                      \
     _Pragma("unroll") for (int j = 0; j < NPASS; ++j) {                                                  \
       const unsigned dst_ = lds_base + (unsigned)(((STG)*STAGE + l_r0[j] * W4BK) * sizeof(float));       \
+      if (UOC_W4_ABLATE == 4) continue;                                                                  \
       if (j < NPA)                                                                                       \
         blds16(srd_a, l_voff[j], soff_a, dst_);                                                          \
       else                                                                                               \
@@ -298,11 +311,11 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
   if (nchunks > 1) {
     W4_ISSUE(1)
     W4_ADVANCE()
-    wait_vmcnt<NPASS>();
+    w4_wait_vmcnt<NPASS>();
   } else {
-    wait_vmcnt<0>();
+    w4_wait_vmcnt<0>();
   }
-  __builtin_amdgcn_s_barrier();
+  W4_BARRIER();
   W4_FRAG(0, 0, wa0, xb0)
   int s_cur = 0, s_nxt = 1, s_nn = 2;  // ring positions of chunks kc, kc+1, kc+2
   const bool early = wave < 4;         // waves w and w+4 share a SIMD: they issue their DMA bursts at different points
@@ -325,11 +338,11 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
     // epilogue (below) are counted by vmcnt as well; they only make this wait conservative (loads retire in order
     // among themselves, so "at most NPASS outstanding" always implies chunk kc+1's loads are done).
     if (kc + 2 < nchunks)
-      wait_vmcnt<NPASS>();
+      w4_wait_vmcnt<NPASS>();
     else
-      wait_vmcnt<0>();
+      w4_wait_vmcnt<0>();
     __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the h=1 fragment reads
-    __builtin_amdgcn_s_barrier();
+    W4_BARRIER();
     if (kc + 1 < nchunks) W4_FRAG(s_nxt, 0, wa0, xb0)
     __builtin_amdgcn_sched_barrier(0);
     W4_MFMA_E(wa1, xb1, x)
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int m = mt * BM + wm * WM + 16 * i + t;
-          if (m < NT)
+          if (m < NT)   // plain stores: the non-temporal hint here was measured slower (179-181 -> 184-187 us per launch, round 4)
             *reinterpret_cast<float4 *>(dst + (size_t)m * Cout + co) =
                 make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
           acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
