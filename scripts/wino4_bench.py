@@ -18,6 +18,9 @@ shapes = [  # name, B, H, W, C, dil
     ("s2 layer3 256 d2 28x28x28", 28, 28, 28, 256, 2),
     ("s2 layer2 128 d1 28x28x28", 28, 28, 28, 128, 1),
     ("s1 layer4 512 d4 1x60x80", 1, 60, 80, 512, 4),
+    # round 4, VERDICT item 5 (F(3x3) remainder tiles for the 7x7 phase images of the crops): the plane GEMM a tile CLASS
+    # of that scheme would run — ONE tile per phase image (28 crops x 16 phases = 448 rows per plane) instead of four
+    ("s2 layer4 one tile per phase image 28x16x16", 28, 16, 16, 512, 4),
 ]
 
 
