@@ -26,8 +26,10 @@ from . import mean_shift_oracle as MS
 
 # Perturbation bound used by the parity tests (DESIGN.md section 5 derives it):
 #   |delta margin| <= 2 * 0.5 * (|dx| + |dz|)  with  |dx| = L2 error of a pixel's embedding, |dz| = L2 error of a seed
-# measured on the bench frames (tests/test_headline_parity_gpu.py states the live values next to these bars):
-#   |dx| <= 1.2e-5  (64 components of <= 2.5e-6, typically 1e-6), |dz| <= 4e-4 (ten kappa = 20 iterations amplify it).
+# measured on the bench frames (tests/test_headline_parity_gpu.py::test_tau_is_the_measured_perturbation states the live
+# values, profiles/r04_parity_tau.json): |dx| = 2.0e-6 .. 2.3e-6; |dz| of 99 % of the seeds 2e-7 .. 9e-7 (a well supported
+# seed CONTRACTS the error), sparsely supported seeds up to 3.9e-4 (largest of 2 400 seeds) — and the largest margin of a
+# pixel that actually differs over 1 024 frames is 3.9e-4 as well (profiles/r04_parity_margins.json).
 TAU = 5e-4
 TAU_STORE = 2e-3        # sparse fixtures keep every pixel below this
 

@@ -299,9 +299,17 @@ def test_tau_is_the_measured_perturbation(device, nets):
         row["near_tie_set_reproduced"] = bool(np.isfinite(stored).all() and np.abs(stored - valF).max() < 1e-4)
         rows.append(row)
     worst = max(r[t]["dx"] + r[t]["dz"] for r in rows for t in ("stage1", "crops"))
-    out = {"tau": M.TAU, "worst_dx_plus_dz": worst, "frames": rows}
+    seeds = sum(r[t]["seeds"] for r in rows for t in ("stage1", "crops"))
+    moved = sum(r[t]["seeds_moved_more_than_tau"] for r in rows for t in ("stage1", "crops"))
+    dz_max = max(r[t]["dz_max"] for r in rows for t in ("stage1", "crops"))
+    out = {"tau": M.TAU, "worst_dx_plus_dz_q99": worst, "largest_seed_movement": dz_max, "seeds": seeds,
+           "seeds_moved_more_than_tau": moved, "frames": rows}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "parity_tau.json"), "w"), indent=1)
     print(json.dumps(out))
+    # TAU bounds what the embedding error does to a margin: |dx| + the movement of the two seeds involved.  Well supported
+    # seeds contract the error (q99 of |dz| < |dx|); sparsely supported ones amplify it up to a few 1e-4 (measured maximum
+    # over 2 400 seeds: 3.9e-4); seeds beyond TAU must be rare — they are the ones (c) hands to the perturbation analysis
     assert worst <= M.TAU, out
+    assert moved <= 0.005 * seeds, out
     assert all(r["near_tie_set_reproduced"] for r in rows), rows
