@@ -41,7 +41,7 @@ struct uoc_net {
   int stem = -1, fc = -1;
   bool finalized = false;
   int device = -1;
-  int wino_min_cin = 128;  // 3x3 stride-1 layers with Cin >= this run as Winograd convolutions; 0 = never
+  int wino_min_cin = 64;   // 3x3 stride-1 layers with Cin >= this run as Winograd convolutions; 0 = never (round 4: 64, was 128)
   int wino_f = 4;          // output tile of the Winograd path: 4 = F(4x4,3x3) (csrc/wino4.hip), 2 = F(2x2,3x3) (csrc/wino.hip)
   int mode = UOC_NET_RGBD_ADD;
   int G = 2;  // backbones evaluated side by side (2 for RGBD 'add' and 'cat')
@@ -168,9 +168,10 @@ static int finalize_layer(uoc_net *n, ConvLayer &L) {
   UOC_HIP_CHECK(hipMalloc(&L.d_b, hb.size() * sizeof(float)));
   UOC_HIP_CHECK(hipMemcpy(L.d_w, hw.data(), hw.size() * sizeof(float), hipMemcpyHostToDevice));
   UOC_HIP_CHECK(hipMemcpy(L.d_b, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
-  // Measured on MI355X (scripts/conv_microbench.py): Winograd wins from 256 input channels up
-  // (layer4 1.4x, layer3 1.0-1.2x) and loses below (the transforms dominate), hence the static rule.
-  // Static, not autotuned: the two algorithms round differently, and results must not depend on timing.
+  // Which layers run as Winograd is a STATIC rule (Cin >= wino_min_cin), not autotuned: the two algorithms round
+  // differently, and results must not depend on timing.  F(4x4): every 3x3 stride-1 layer from 64 channels up since
+  // round 4 (layer1 too: with the non-temporal frequency-plane accesses its transforms stopped costing more than the 4x
+  // fewer MFMAs save — same-box A/B 165.3 / 165.9 -> 167.4 / 167.6 frames/s; round 3 had measured 160.3 vs 160.2).
   if (!L.stem && L.K == 3 && L.stride == 1 && n->wino_min_cin > 0 && L.Cin >= n->wino_min_cin && L.Cin % 32 == 0 &&
       L.Cout % 64 == 0) {
     if (n->wino_f == 4 && !wino4_channels_ok(L.Cin, L.Cout)) {
