@@ -219,7 +219,7 @@ def parity_report(gpu_maps, cpu_npz, network=None, network_crop=None, device=Non
         return rep
     from unseenobjectclustering_amd import runner
     from unseenobjectclustering_amd.fcn import test_dataset as TD
-    worst, s1_exact, given_exact, used, given_bad = 0.0, True, True, 0, []
+    worst, s1_exact, given_exact, used, given_bad, given_beyond = 0.0, True, True, 0, [], 0
     # the oracle's maps of the same frames from ANOTHER host (tests/golden/bench_oracle: the build container, 4 threads)
     import glob
     fixture = {}
@@ -247,6 +247,11 @@ def parity_report(gpu_maps, cpu_npz, network=None, network_crop=None, device=Non
         given_exact = given_exact and bool(O.labels_equal_up_to_permutation(out_b[0].numpy(), want1[g])) \
             and bool(O.labels_equal_up_to_permutation(fin_b, want[g]))
         given_bad.append(_mismatched_pixels(fin_b, want[g]))
+        if given_bad[-1] and g in near:      # the oracle's own last pixels move with the thread count / host: margin rule here too
+            bad_px = MG.label_changes(want[g], fin_b)
+            given_beyond += int((MG.lookup_margins(near[g]["idxF"], near[g]["valF"], bad_px) > MG.TAU).sum())
+        elif given_bad[-1]:
+            given_beyond += given_bad[-1]
         if g in fixture:
             given_bad_fix.append(_mismatched_pixels(fin_b, fixture[g]))
             oracle_vs_fix.append(_mismatched_pixels(want[g], fixture[g]))
@@ -256,7 +261,8 @@ def parity_report(gpu_maps, cpu_npz, network=None, network_crop=None, device=Non
         s1_exact = s1_exact and bool(O.labels_equal_up_to_permutation(out_c[0].numpy(), want1[g]))
     rep.update({"decomposed_frames": used, "embed_max_err": worst, "embed_tolerance": 1e-3,
                 "exact_given_oracle_embeddings": given_exact if used else None,
-                "given_oracle_embeddings_mismatched_pixels": given_bad, "stage1_exact": s1_exact if used else None,
+                "given_oracle_embeddings_mismatched_pixels": given_bad, "given_oracle_embeddings_beyond_margin": given_beyond,
+                "stage1_exact": s1_exact if used else None,
                 "given_oracle_embeddings_mismatched_pixels_vs_fixture_oracle": given_bad_fix or None,
                 "this_oracle_run_vs_fixture_oracle_mismatched_pixels": oracle_vs_fix or None,
                 "note": "mismatched_pixels = end to end (HIP embeddings -> HIP integer path); *given_oracle_embeddings* = the "
@@ -358,8 +364,9 @@ def compact_line(full, full_path):
     if out["cpu_baseline"] and out["cpu_baseline"].get("sample"):
         out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:110]
     par = full.get("parity")
-    out["parity"] = _pick(par, ("frames", "embed_max_err", "exact_given_oracle_embeddings", "stage1_exact",
-                                "mismatched_pixels", "mismatches_beyond_margin"))
+    out["parity"] = _pick(par, ("frames", "embed_max_err", "stage1_exact", "mismatched_pixels", "mismatches_beyond_margin",
+                                "given_oracle_embeddings_mismatched_pixels", "given_oracle_embeddings_beyond_margin",
+                                "given_oracle_embeddings_mismatched_pixels_vs_fixture_oracle"))
     lat = full.get("latency")
     out["latency"] = _pick(lat, ("ms_per_frame", "frames_per_s"))
     sus = full.get("sustained")

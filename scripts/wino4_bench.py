@@ -28,6 +28,7 @@ def measure(B, H, W, C, dil, env, iters=10):
     for k in ("UOC_CONV_WINOGRAD", "UOC_WINO4_GEMM", "UOC_WINO4_TILE"):
         os.environ.pop(k, None)
     os.environ.update(env)
+    L.uoc_reload_env()          # the library caches its knobs
     x = torch.randn(G, B, H, W, C, device=dev)
     w = torch.randn(G, 9, C, C, device=dev) * 0.02
     b = torch.randn(G, C, device=dev)

@@ -464,8 +464,9 @@ int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, co
   p.stem = 0;
   p.Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   p.Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
-  const char *force = getenv("UOC_CONV_WINOGRAD");  // test / micro-benchmark hook: 1 = Winograd F(2x2), 4 = F(4x4) for eligible shapes
-  if (force && atoi(force) == 4 && wino4_eligible(p)) {
+  static EnvInt force_env("UOC_CONV_WINOGRAD", 0);  // test / micro-benchmark hook: 1 = Winograd F(2x2), 4 = F(4x4) for eligible shapes (cached: uoc_reload_env)
+  const int force = force_env.get();
+  if (force == 4 && wino4_eligible(p)) {
     static float *U4 = nullptr, *ws4 = nullptr;
     static size_t ucap4 = 0, wcap4 = 0;
     static const float *u4_for = nullptr;
@@ -486,7 +487,7 @@ int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, co
     if (int rc = launch_wino4_weights(d_w, U4, G, Cout, Cin, st)) return rc;
     return launch_wino4_conv(p, U4, ws4, st);
   }
-  if (force && atoi(force) == 1 && wino_eligible(p)) {
+  if (force == 1 && wino_eligible(p)) {
     // scratch owned by this entry (kept between calls; the network path gets its scratch from the caller)
     static float *U = nullptr, *V = nullptr;
     static size_t ucap = 0, vcap = 0;
