@@ -177,7 +177,13 @@ __device__ __forceinline__ void w4_wait_vmcnt() {
   if (UOC_W4_ABLATE != 2) wait_vmcnt<N>();
 }
 
-template <int BM, int BN>
+// PAIR (round 4): a 4-stage ring and ONE barrier per TWO K-chunks.  The barrier costs 5-9 % of the kernel (15 % on 4-chunk
+// items: timing ablation, profiles/r04_pmc_mfma.md); a pair of chunks is fetched two chunks ahead into the two stages the
+// previous pair has just left, so the barrier at the end of a pair covers both hazards (the DMA'd rows of the next pair are
+// visible to every wave; every wave has finished reading the stages the pair after next will overwrite).  The items of a
+// block always hold an even number of chunks (Cin / 32 = 2, 4, 8, 16), so a pair never straddles two items.  Same MFMA
+// order per accumulator as the single-chunk loop: bit-identical results.
+template <int BM, int BN, bool PAIR>
 __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
                                                          float *__restrict__ Mo, int NT, int Cin, int Cout, int planes,
                                                          int mtiles, int nt_shift) {
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
   constexpr int STAGE = R * W4BK;
   static_assert(WM % 16 == 0 && WN % 16 == 0 && R % 8 == 0 && NPASS <= 8, "tile shape");
 
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3][R][32]
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // [3 | 4][R][32]
 
   const int ntiles = 1 << nt_shift;
   const int per_plane = mtiles << nt_shift;
@@ -305,6 +311,92 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
   int cmp_plane = iss_plane, cmp_rem = iss_rem, cmp_cc = 0;
 
   float4 wa0[TN], xb0[TM], wa1[TN], xb1[TM];
+  const bool early = wave < 4;         // waves w and w+4 share a SIMD: they issue their DMA bursts at different points
+  auto epilogue = [&]() {   // item complete: store its accumulators into the plane, start the next item from zero
+    cmp_cc = 0;
+    const int mt = cmp_rem >> nt_shift, nt = cmp_rem & (ntiles - 1);
+    float *dst = Mo + (size_t)cmp_plane * NT * Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int co = nt * BN + wn * WN + 16 * j + 4 * q;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = mt * BM + wm * WM + 16 * i + t;
+        if (m < NT)   // plain stores: the non-temporal hint here was measured slower (179-181 -> 184-187 us per launch, round 4)
+          *reinterpret_cast<float4 *>(dst + (size_t)m * Cout + co) =
+              make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+        acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    cmp_rem += nbl;
+    while (cmp_rem >= per_plane) {
+      cmp_rem -= per_plane;
+      ++cmp_plane;
+    }
+  };
+  if constexpr (PAIR) {
+    W4_ITEM_SETUP()
+    W4_ISSUE(0)
+    W4_ADVANCE()
+    W4_ISSUE(1)
+    W4_ADVANCE()
+    w4_wait_vmcnt<0>();
+    W4_BARRIER();
+    W4_FRAG(0, 0, wa0, xb0)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    for (int kc = 0; kc < nchunks; kc += 2) {
+      const int sa = (kc & 2), sb = sa + 1, sc = sa ^ 2, sd = sc + 1;   // stages of this pair / of the next
+      const bool more = kc + 2 < nchunks;
+      if (more && early) {
+        W4_ISSUE(sc)
+        W4_ADVANCE()
+        W4_ISSUE(sd)
+        W4_ADVANCE()
+      }
+      W4_MFMA_E(wa0, xb0, x)
+      W4_FRAG(sa, 1, wa1, xb1)
+      __builtin_amdgcn_sched_barrier(0);
+      W4_MFMA_E(wa0, xb0, y)
+      W4_MFMA_E(wa0, xb0, z)
+      W4_MFMA_E(wa0, xb0, w)
+      if (more && !early) {
+        W4_ISSUE(sc)
+        W4_ADVANCE()
+        W4_ISSUE(sd)
+        W4_ADVANCE()
+      }
+      W4_FRAG(sb, 0, wa0, xb0)   // the pair's second chunk landed before the previous barrier
+      __builtin_amdgcn_sched_barrier(0);
+      W4_MFMA_E(wa1, xb1, x)
+      W4_MFMA_E(wa1, xb1, y)
+      W4_MFMA_E(wa1, xb1, z)
+      W4_MFMA_E(wa1, xb1, w)
+      __builtin_amdgcn_sched_barrier(0);
+      W4_MFMA_E(wa0, xb0, x)
+      W4_FRAG(sb, 1, wa1, xb1)
+      __builtin_amdgcn_sched_barrier(0);
+      W4_MFMA_E(wa0, xb0, y)
+      W4_MFMA_E(wa0, xb0, z)
+      W4_MFMA_E(wa0, xb0, w)
+      if (more) {
+        w4_wait_vmcnt<0>();                  // the next pair has landed (issued ~1.5 chunks ago)
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's reads of the pair's stages are done
+        W4_BARRIER();
+        W4_FRAG(sc, 0, wa0, xb0)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      W4_MFMA_E(wa1, xb1, x)
+      W4_MFMA_E(wa1, xb1, y)
+      W4_MFMA_E(wa1, xb1, z)
+      W4_MFMA_E(wa1, xb1, w)
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_sched_barrier(0);
+      cmp_cc += 2;
+      if (cmp_cc == cpt) epilogue();
+    }
+    return;
+  }
   W4_ITEM_SETUP()
   W4_ISSUE(0)
   W4_ADVANCE()
@@ -318,7 +410,6 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
   W4_BARRIER();
   W4_FRAG(0, 0, wa0, xb0)
   int s_cur = 0, s_nxt = 1, s_nn = 2;  // ring positions of chunks kc, kc+1, kc+2
-  const bool early = wave < 4;         // waves w and w+4 share a SIMD: they issue their DMA bursts at different points
   // The second-dispatched half of the block loses the issue arbitration against its SIMD partner (priority, then age:
   // MI355X_MICROARCH.md, "Two waves per SIMD", item 4): one static priority bump for it, no per-phase flips.
   // Measured alone: layer4 412 -> 402 us, 28-crop layer4 533 -> 528 us, the short-K shapes unchanged; in the
@@ -352,28 +443,7 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_sched_barrier(0);
-    if (++cmp_cc == cpt) {  // item complete: store its accumulators into the plane, start the next item from zero
-      cmp_cc = 0;
-      const int mt = cmp_rem >> nt_shift, nt = cmp_rem & (ntiles - 1);
-      float *dst = Mo + (size_t)cmp_plane * NT * Cout;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int co = nt * BN + wn * WN + 16 * j + 4 * q;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int m = mt * BM + wm * WM + 16 * i + t;
-          if (m < NT)   // plain stores: the non-temporal hint here was measured slower (179-181 -> 184-187 us per launch, round 4)
-            *reinterpret_cast<float4 *>(dst + (size_t)m * Cout + co) =
-                make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-          acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      }
-      cmp_rem += nbl;
-      while (cmp_rem >= per_plane) {
-        cmp_rem -= per_plane;
-        ++cmp_plane;
-      }
-    }
+    if (++cmp_cc == cpt) epilogue();
     const int tmp = s_cur;
     s_cur = s_nxt;
     s_nxt = s_nn;
@@ -386,22 +456,24 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
 #undef W4_MFMA_E
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool PAIR>
 static int launch_wino4_gemm_t(const float *V, const float *U, float *Mo, int NT, int Cin, int Cout, int planes, int nblocks,
                                hipStream_t st) {
   const int mtiles = (NT + BM - 1) / BM, ntiles = Cout / BN;
   int nt_shift = 0;
   while ((1 << nt_shift) < ntiles) ++nt_shift;
   UOC_REQUIRE((1 << nt_shift) == ntiles, "winograd F(4x4): Cout / %d = %d is not a power of two", BN, ntiles);
-  const size_t lds = (size_t)3 * (BM + BN) * W4BK * sizeof(float);
-  static_assert((size_t)3 * (BM + BN) * W4BK * sizeof(float) <= 160 * 1024, "LDS ring too large");
+  constexpr int NSTAGE = PAIR ? 4 : 3;
+  const size_t lds = (size_t)NSTAGE * (BM + BN) * W4BK * sizeof(float);
+  static_assert((size_t)NSTAGE * (BM + BN) * W4BK * sizeof(float) <= 160 * 1024, "LDS ring too large");
+  UOC_REQUIRE(!PAIR || (Cin / W4BK) % 2 == 0, "winograd F(4x4): the pair loop needs an even number of 32-channel chunks");
   static DeviceOnce attr_set;
   if (!attr_set.done()) {
-    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&wino4_gemm_kernel<BM, BN>),
+    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&wino4_gemm_kernel<BM, BN, PAIR>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set.mark();
   }
-  hipLaunchKernelGGL((wino4_gemm_kernel<BM, BN>), dim3(nblocks), dim3(512), lds, st, V, U, Mo, NT, Cin, Cout, planes, mtiles,
+  hipLaunchKernelGGL((wino4_gemm_kernel<BM, BN, PAIR>), dim3(nblocks), dim3(512), lds, st, V, U, Mo, NT, Cin, Cout, planes, mtiles,
                      nt_shift);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
@@ -459,8 +531,16 @@ static int launch_wino4_gemm(const float *V, const float *U, float *Mo, int NT, 
       nblocks = 8 * (int)(S < ncu / 8 ? S : ncu / 8);
     }
   }
-#define W4_CASE(A, B) \
-  if (bm == A && bn == B) return launch_wino4_gemm_t<A, B>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
+  // UOC_W4_PAIR (A/B): 0 = the 3-stage ring with one barrier per chunk (round 3) everywhere.  Measured per launch shape,
+  // same box: layer4 383 -> 377 / 569 -> 551 / 533 -> 516 us, layer3 117.4 -> 115.8 / 165 -> 161 / 150.5 -> 147 us, layer2
+  // equal, the 2-chunk items of layer1 45.0 -> 45.6 us (worse: they keep the single-chunk loop); class average 154 -> 151.5 us
+  static EnvInt pair_env("UOC_W4_PAIR", 1);
+  const int cpt = Cin / W4BK;
+  const bool pair = pair_env.get() != 0 && cpt % 2 == 0 && cpt >= 4;
+#define W4_CASE(A, B)                                                                                                \
+  if (bm == A && bn == B)                                                                                            \
+    return pair ? launch_wino4_gemm_t<A, B, true>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st)                       \
+                : launch_wino4_gemm_t<A, B, false>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
   W4_CASE(96, 128) W4_CASE(128, 128) W4_CASE(160, 128) W4_CASE(192, 128)
   W4_CASE(96, 64) W4_CASE(128, 64) W4_CASE(160, 64) W4_CASE(192, 64)
 #undef W4_CASE
