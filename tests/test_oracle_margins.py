@@ -1,0 +1,94 @@
+"""oracle/margins.py on the CPU: the decision margins behind the margin-bounded end-to-end parity test
+(tests/test_headline_parity_gpu.py) — against brute force on a small field, on the oracle's own two-stage run of a small
+frame, and the committed near-tie sets of the 1 024 benchmark frames (tests/golden/bench_margins)."""
+import glob
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import glue_oracle as GO, margins as M, mean_shift_oracle as O
+from unseenobjectclustering_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_assign_margins_against_brute_force():
+    g = torch.Generator().manual_seed(5)
+    X = F.normalize(torch.randn(500, 64, generator=g), dim=1)
+    Z = F.normalize(torch.randn(12, 64, generator=g), dim=1)
+    labels = torch.tensor([0, 0, 1, 2, 2, 2, 3, 1, 0, 3, 3, 2])
+    got = M.assign_margins(X, Z, labels, chunk=128).numpy()
+    d = (0.5 * (1 - X @ Z.t())).numpy()
+    for p in range(500):
+        best = int(np.argmin(d[p]))
+        other = d[p][labels.numpy() != int(labels[best])].min()
+        assert abs(got[p] - (other - d[p, best])) < 1e-6
+    assert (got >= 0).all()
+    # one label only: nothing can flip
+    assert np.isinf(M.assign_margins(X, Z, torch.zeros(12, dtype=torch.long)).numpy()).all()
+
+
+def test_label_changes_is_invariant_to_a_permutation_of_the_ids():
+    rng = np.random.default_rng(0)
+    base = rng.integers(0, 5, size=(40, 50))
+    perm = np.array([3, 0, 4, 1, 2])
+    assert len(M.label_changes(base, perm[base])) == 0
+    other = perm[base].copy()
+    other[7, 9] = perm[(base[7, 9] + 1) % 5]
+    other[30, 2] = perm[(base[30, 2] + 2) % 5]
+    assert sorted(M.label_changes(base, other).tolist()) == [7 * 50 + 9, 30 * 50 + 2]
+
+
+def test_sparse_lookup_round_trip():
+    m = np.full((6, 7), np.inf, np.float32)
+    m[1, 2], m[4, 4], m[5, 0] = 1e-4, 5e-4, 3e-3
+    idx, val = M.sparse_below(m, 2e-3)
+    assert idx.tolist() == [9, 32] and np.allclose(val, [1e-4, 5e-4])
+    got = M.lookup_margins(idx, val, np.array([9, 10, 32, 35, 0]))
+    assert np.allclose(got[[0, 2]], [1e-4, 5e-4]) and np.isinf(got[[1, 3, 4]]).all()
+    assert len(M.lookup_margins(idx, val, np.zeros(0, np.int64))) == 0
+
+
+def _stub_features(seed, H, W, k):
+    X, _ = synth.embedding_field(seed, H, W, 64, k, 0.05)
+    return torch.from_numpy(X).view(H, W, 64).permute(2, 0, 1)[None].contiguous()
+
+
+def test_two_stage_run_with_margins_equals_the_pinned_oracle_and_bounds_perturbations():
+    """test_sample_with_margins must return exactly glue_oracle.test_sample's maps (it only keeps intermediates), and a
+    perturbation of the embeddings far below the smallest margin must not change a pixel with a larger margin."""
+    H, W = 96, 128
+    fr = synth.rgbd_frame(11, H, W, 3, hole_fraction=0.0)
+    img, dep = torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"])
+    s1 = lambda i, l, d: _stub_features(40, H, W, 4)
+    s2 = lambda i, l, d: torch.cat([_stub_features(50 + j, 224, 224, 2 + j % 2) for j in range(i.shape[0])])
+    out, ref, info = M.test_sample_with_margins(img, dep, s1, s2, np.random.RandomState(7))
+    want_out, want_ref = GO.test_sample(img, dep, s1, s2, np.random.RandomState(7))
+    assert torch.equal(out, want_out) and torch.equal(ref, want_ref)
+    assert info["marginF"].shape == (H, W) and info["margin1"].shape == (H * W,)
+    assert info["rois"].shape[0] == info["X2"].shape[0] >= 1
+    inside = np.zeros((H, W), bool)
+    for x0, y0, x1, y1 in info["rois"]:
+        inside[y0:y1 + 1, x0:x1 + 1] = True
+    assert np.isfinite(info["marginF"][inside]).all() and np.isinf(info["marginF"][~inside]).all()
+    # embeddings perturbed by 1e-6 per component: only pixels with a margin below ~1e-4 may change their label
+    eps = 1e-6
+    p1, p2 = M.perturbed_network(s1, eps, 1), M.perturbed_network(s2, eps, 2)
+    o2, r2 = GO.test_sample(img, dep, p1, p2, np.random.RandomState(7))
+    changed = M.label_changes(ref[0].numpy(), r2[0].numpy())
+    assert (info["marginF"].reshape(-1)[changed] <= 1e-4).all()
+
+
+def test_committed_bench_margins_cover_the_benchmark_frames():
+    mar = M.load_bench_margins(ROOT)
+    assert sorted(mar) == list(range(1024)), "tests/golden/bench_margins must hold all 1 024 frames of BASELINE configs[4]"
+    n_oracle = sum(len(np.load(p)["final"]) for p in glob.glob(os.path.join(ROOT, "tests", "golden", "bench_oracle", "frames_*.npz")))
+    assert n_oracle == 1024
+    for g in (0, 246, 639, 1023):
+        r = mar[g]
+        for k in ("idx1", "idxF"):
+            assert (np.diff(r[k].astype(np.int64)) > 0).all() and (len(r[k]) == 0 or r[k].max() < 480 * 640)
+        assert (r["valF"] <= M.TAU_STORE + 1e-9).all() and (r["valF"] >= 0).all() and 5 <= len(r["rois"]) <= 8
+    assert M.TAU < M.TAU_STORE
