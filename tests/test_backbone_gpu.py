@@ -265,3 +265,27 @@ def test_fused_transforms_are_bit_identical(device, shape):
         L.uoc_reload_env()
     assert torch.equal(fused, separate)
     assert torch.isfinite(fused).all()
+
+
+@pytest.mark.parametrize("shape", [(1, 480, 640), (5, 224, 224), (1, 72, 104), (3, 61, 83)])
+def test_small_k_fused_gemm_is_bit_identical(device, shape):
+    """Round 4 experiment, opt-in (UOC_WINO4_SMALL=1; measured slower, csrc/wino4.hip wino4_small_ok): the 64- and 128-channel
+    F(4x4) layers with their 72 plane GEMMs and the output transform as ONE kernel (all 36 plane accumulators of a 16 x 16
+    tile in registers, no M planes).  Same MFMA order per accumulator and the same transform functions as the separate
+    kernels: it must give the same bits."""
+    B, H, W = shape
+    net, _ = _net(4, device)
+    g = torch.Generator().manual_seed(H * W + 7 * B)
+    img = torch.randn(B, 3, H, W, generator=g).to(device)
+    xyz = torch.randn(B, 3, H, W, generator=g).to(device)
+    L = _native.lib()
+    separate = net(img, None, xyz).clone()
+    os.environ["UOC_WINO4_SMALL"] = "1"
+    L.uoc_reload_env()
+    try:
+        fused = net(img, None, xyz).clone()
+    finally:
+        os.environ.pop("UOC_WINO4_SMALL", None)
+        L.uoc_reload_env()
+    assert torch.equal(fused, separate)
+    assert torch.isfinite(fused).all()

@@ -49,6 +49,9 @@ int wino4_chain_input(const ConvParams &p, float *V, hipStream_t st);
 int wino4_chain_gemm(const ConvParams &p, const float *U, float *V, float *Mw, hipStream_t st);
 int wino4_chain_output(const ConvParams &p, const float *Mw, hipStream_t st);
 int wino4_chain_mid(const ConvParams &prev, bool write_y, const float *Mw, float *V, hipStream_t st);
+// small-K layers (Cin = Cout = 64 / 128): the 72 plane GEMMs and the output transform as ONE kernel, no M planes
+bool wino4_small_ok(const ConvParams &p);
+int wino4_chain_gemm_out(const ConvParams &p, const float *U, const float *V, hipStream_t st);
 
 // NCHW [B][3][H][W] -> NHWC4 [B][H][W][4] (4th channel = 0)
 int launch_nchw3_to_nhwc4(const float *in, float *out, int B, int H, int W, hipStream_t st);

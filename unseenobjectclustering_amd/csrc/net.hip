@@ -403,6 +403,7 @@ int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, i
         if (int rc = flush()) return rc;
         if (int rc = wino4_chain_input(p, Vp, st)) return rc;
       }
+      if (wino4_small_ok(p)) return wino4_chain_gemm_out(p, L.d_U4, Vp, st);   // small K: GEMMs + output transform in one kernel
       if (int rc = wino4_chain_gemm(p, L.d_U4, Vp, Mp, st)) return rc;
       pend = p;
       pending = true;

@@ -177,6 +177,89 @@ __device__ __forceinline__ void w4_wait_vmcnt() {
   if (UOC_W4_ABLATE != 2) wait_vmcnt<N>();
 }
 
+// ---- small-K layers (Cin = Cout = 64 / 128): plane GEMMs + output transform in ONE kernel, no M planes -------------------
+// With K = 64 a plane GEMM does 32 flop per byte of V + M: the layer is HBM-bound and M (2.25 x the activation, written by
+// the GEMM and read back by the output transform) is 40 % of its traffic.  Here a block owns 16 tiles x all output channels
+// and walks the 36 planes of its branch: wave w owns output channels 16 w .. 16 w + 15 and keeps ALL 36 plane accumulators
+// of its 16 x 16 tile in registers (144 VGPRs), so that after the last plane every lane holds the 36 frequencies of its
+// (tile, 4 channels) and applies A^T . A, bias, residual and ReLU itself (wino4_math.h: the functions of the separate
+// kernels; MFMA order per accumulator = cin order as in the plane GEMM: bit-identical results).  Operands go straight
+// from L2 into registers (one plane ahead), no LDS: U (36 x C x C floats per branch, 0.6 / 2.4 MB) is re-read per 16
+// tiles from L2 instead of M making a round trip through HBM.
+template <int C>
+__global__ __launch_bounds__(C * 4) __attribute__((amdgpu_waves_per_eu(2))) void wino4_small_kernel(const float *__restrict__ V, const float *__restrict__ U,
+                                                            const float *__restrict__ bias, const float *__restrict__ res,
+                                                            float *__restrict__ out, Wino4Geom geo, int G, int relu) {
+  constexpr int KK = C / 16;   // float4 loads per operand row and plane (16 K-steps of 4 per load quartet)
+  const int rtiles = (geo.NT + 15) >> 4;
+  const int g = blockIdx.x / rtiles, rt = blockIdx.x - g * rtiles;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = lane & 15, q = lane >> 4;
+  const int row = min(rt * 16 + t, geo.NT - 1);   // rows beyond the last tile read the last valid row, never stored
+  const size_t plane_v = (size_t)geo.NT * C, plane_u = (size_t)C * C;
+  const float *vp = V + (size_t)g * 36 * plane_v + (size_t)row * C + 4 * q;
+  const float *up = U + (size_t)g * 36 * plane_u + (size_t)(16 * wave + t) * C + 4 * q;
+  f32x4 acc[36];
+  float4 wf[KK], xf[KK], wn[KK], xn[KK];
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    wf[kk] = *reinterpret_cast<const float4 *>(up + 16 * kk);
+    xf[kk] = *reinterpret_cast<const float4 *>(vp + 16 * kk);
+  }
+#pragma unroll
+  for (int xi = 0; xi < 36; ++xi) {
+    if (xi + 1 < 36) {
+#pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        wn[kk] = *reinterpret_cast<const float4 *>(up + (size_t)(xi + 1) * plane_u + 16 * kk);
+        xn[kk] = *reinterpret_cast<const float4 *>(vp + (size_t)(xi + 1) * plane_v + 16 * kk);
+      }
+    }
+    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      a = w4mfma(wf[kk].x, xf[kk].x, a);
+      a = w4mfma(wf[kk].y, xf[kk].y, a);
+      a = w4mfma(wf[kk].z, xf[kk].z, a);
+      a = w4mfma(wf[kk].w, xf[kk].w, a);
+    }
+    acc[xi] = a;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      wf[kk] = wn[kk];
+      xf[kk] = xn[kk];
+    }
+  }
+  const int tau = rt * 16 + t;
+  if (tau >= geo.NT) return;
+  float4 m[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) m[k] = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+  float4 yv[4][4];
+  wino4_output_tile(m, yv);
+  int b, oy, ox;
+  wino4_decode(tau, geo, b, oy, ox);
+  const int ch = 16 * wave + 4 * q;
+  const size_t gsz = (size_t)geo.Bg * geo.H * geo.W * C;
+  float4 bv;
+  if (bias)
+    bv = *reinterpret_cast<const float4 *>(bias + (size_t)g * C + ch);
+  else
+    w4_zero(bv);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int y = oy + a * geo.d;
+    if (y >= geo.H) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int x = ox + e * geo.d;
+      if (x >= geo.W) continue;
+      const size_t o = (size_t)g * gsz + (((size_t)b * geo.H + y) * geo.W + x) * C + ch;
+      *reinterpret_cast<float4 *>(out + o) = wino4_epilogue(yv[a][e], bv, res ? res + o : nullptr, relu);
+    }
+  }
+}
+
 // PAIR (round 4): a 4-stage ring and ONE barrier per TWO K-chunks.  The barrier costs 5-9 % of the kernel (15 % on 4-chunk
 // items: timing ablation, profiles/r04_pmc_mfma.md); a pair of chunks is fetched two chunks ahead into the two stages the
 // previous pair has just left, so the barrier at the end of a pair covers both hazards (the DMA'd rows of the next pair are
@@ -760,6 +843,32 @@ int wino4_chain_gemm(const ConvParams &p, const float *U, float *V, float *Mw, h
 }
 int wino4_chain_output(const ConvParams &p, const float *Mw, hipStream_t st) {
   return w4_stage_output(p, make_geom4(p.B, p.H, p.W, p.dil), Mw, st);
+}
+
+// plane GEMMs + output transform of a small-K layer in one kernel (wino4_small_kernel): V planes -> p.out
+bool wino4_small_ok(const ConvParams &p) {
+  // OFF by default: built, bit-identical, measured SLOWER (round 4, same box): 135 us against 45 + 36 us (plane GEMM +
+  // output transform) on stage-1 layer1, 137 against 40 + 20 us on layer2; 158.5 vs 166.9 frames/s.  Keeping 36 plane
+  // accumulators per lane limits a wave to a 16 x 16 tile: 512 operand bytes per MFMA from L2 (the 160 x 128 block of the
+  // plane GEMM needs 57), one plane of prefetch (0.2 us of MFMAs) cannot cover the L2 latency, and the register budget
+  // allows neither a larger tile nor a deeper prefetch.
+  static EnvInt on("UOC_WINO4_SMALL", 0);
+  return on.get() != 0 && p.Cin == p.Cout && (p.Cin == 64 || p.Cin == 128);
+}
+
+int wino4_chain_gemm_out(const ConvParams &p, const float *U, const float *V, hipStream_t st) {
+  const Wino4Geom geo = make_geom4(p.B, p.H, p.W, p.dil);
+  const int grid = p.G * ((geo.NT + 15) / 16);
+  const double Mpix = (double)p.B * p.H * p.W;
+  const ProfTag tag = {{geo.NT, p.Cin, p.Cout, p.dil}};
+  ProfScope prof(KC_WINO4_SMALL, st, 2.0 * Mpix * p.Cout * p.Cin * 9.0 * p.G,
+                 4.0 * p.G * (36.0 * geo.NT * p.Cin + 36.0 * p.Cout * p.Cin + Mpix * p.Cout * (p.res ? 2 : 1)), tag);
+  if (p.Cin == 64)
+    hipLaunchKernelGGL(wino4_small_kernel<64>, dim3(grid), dim3(256), 0, st, V, U, p.bias, p.res, p.out, geo, p.G, p.relu);
+  else
+    hipLaunchKernelGGL(wino4_small_kernel<128>, dim3(grid), dim3(512), 0, st, V, U, p.bias, p.res, p.out, geo, p.G, p.relu);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
 }
 
 // prev's output transform (bias, residual, ReLU; its NHWC tensor prev.out is written only if write_y) + the next layer's
