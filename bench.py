@@ -461,13 +461,17 @@ def main():
     else:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a ROCm device: the product path has no CPU fallback")
-        torch.cuda.set_device(local_rank)
-        device, backend, h, w = torch.device("cuda", local_rank), "nccl", H, W
+        # UOC_BENCH_ONE_DEVICE=1 + UOC_BENCH_BACKEND=gloo (tests only): every rank on GPU 0, label maps gathered through
+        # gloo (staged through the host by runner.run_sharded) — the REAL frame function at world size > 1 on a box with
+        # one GPU (RCCL refuses two ranks on one device); the driver's multi-GPU runs use neither knob
+        dev_index = 0 if os.environ.get("UOC_BENCH_ONE_DEVICE") == "1" else local_rank
+        torch.cuda.set_device(dev_index)
+        device, backend, h, w = torch.device("cuda", dev_index), os.environ.get("UOC_BENCH_BACKEND", "nccl"), H, W
     use_dist = world > 1 or os.environ.get("UOC_BENCH_FORCE_DIST") == "1"   # FORCE: exercise the RCCL path on 1 GPU
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        kw = {} if stub else {"device_id": device}
+        kw = {} if stub or backend != "nccl" else {"device_id": device}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     from unseenobjectclustering_amd import runner

@@ -91,14 +91,19 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     if not collective:
         return block[:hi - lo]
     t_gather = time.perf_counter()
-    flag = torch.tensor([1 if error is not None else 0], dtype=torch.int32, device=device)
+    # gloo has no device collectives for all_gather: a CUDA block is staged through the host (tests that run several ranks
+    # on one GPU; on the GPU node the backend is nccl = RCCL and everything stays on the device)
+    staged = device.type == "cuda" and dist.get_backend() == "gloo"
+    coll_dev = torch.device("cpu") if staged else device
+    flag = torch.tensor([1 if error is not None else 0], dtype=torch.int32, device=coll_dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     if int(flag.item()) != 0:
         if error is not None:
             raise error
         raise RuntimeError("another rank failed in its frame block; aborting before the all_gather")
-    full = torch.empty((world * per, height, width), dtype=torch.uint8, device=device)
-    dist.all_gather_into_tensor(full, block)
+    full = torch.empty((world * per, height, width), dtype=torch.uint8, device=coll_dev)
+    dist.all_gather_into_tensor(full, block.to(coll_dev))
+    full = full.to(device)
     if timing is not None:
         if device.type == "cuda":
             torch.cuda.synchronize(device)
