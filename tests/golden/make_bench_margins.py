@@ -9,7 +9,12 @@ nearest-seed decision is within TAU_STORE = 2e-3 of flipping (sparse: flat index
 slack of the cluster-level decisions.  The maps of this run are compared with bench_oracle's (another run of the same
 oracle: 4 torch threads instead of 1): `differs_from_bench_oracle` holds, per frame, the pixels that differ in the stage-1
 map, in the final map, and how many of them lie beyond TAU (the oracle's last pixels depend on the thread count and the
-host, profiles/r03_oracle_thread_sensitivity_gpu_box.json).  ~19 s per frame on one thread."""
+host, profiles/r03_oracle_thread_sensitivity_gpu_box.json).  ~19 s per frame on one thread.
+
+Provenance of the committed files (round 4): frames 0-191 and 256-383 were computed in the build container (Xeon, one torch
+thread per process), frames 192-255 and 384-1023 on the GPU box's host cores (EPYC 9575F, one thread per process, 8-frame
+sub-blocks through scripts/margins_on_box.sh, merged by merge_bench_margins.py).  Over all 1 024 frames this 1-thread run
+differs from bench_oracle's 4-thread run on 48 frames, on 2 of them beyond TAU (a seed between two modes)."""
 import glob
 import os
 import sys
