@@ -213,7 +213,7 @@ def test_end_to_end_margin_bounded(device, nets):
     # Frames with a pixel beyond the margin: either a regression, or a seed between two modes (oracle/margins.py: the
     # margin bounds the assignment GIVEN the seeds; at such a seed the oracle's own result flips with the last bit of a
     # sum — bench frame 246: 1 vs 4 torch threads).  Ask the oracle: its whole path again with the embeddings perturbed by
-    # the measured embedding error (seeded sign patterns; at least 3 runs) and once on the HIP networks' embeddings; every mismatching pixel must
+    # the measured embedding error (seeded sign patterns; at least 3 runs, up to 24, the late ones at 2x / 4x) and once on the HIP networks' embeddings; every mismatching pixel must
     # be one whose label changes in at least one of those runs, or a near-tie of this host's oracle run, or a pixel on
     # which this host's oracle run itself differs from the committed one.
     assert len(flagged) <= MAX_FLAGGED_FRAMES, [f[0] for f in flagged]
@@ -222,7 +222,7 @@ def test_end_to_end_margin_bounded(device, nets):
     hip2 = lambda image, label, depth: net_crop(image.to(device), None, depth.to(device)).cpu()
     for g, bad, m in flagged:
         img, dep = _bench_frame(g)
-        # pixels the committed near-tie set does not explain: the perturbation runs continue (up to 12) until they do
+        # pixels the committed near-tie set does not explain: the perturbation runs continue (up to 24) until they do
         changed, base, info, used = M.unresolved_pixels(img, dep, cpu_net, runner.frame_rng_seed(g), EMBED_EPS, runs=3,
                                                         extra_networks=[(hip1, hip2)], need=bad[m > M.TAU])
         here_vs_there = M.label_changes(fix[g][1], base)
