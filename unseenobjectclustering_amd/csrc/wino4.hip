@@ -596,9 +596,10 @@ static void pick_wino4_tile(int NT, int Cout, int planes, int &bm, int &bn, int 
 static int launch_wino4_gemm(const float *V, const float *U, float *Mo, int NT, int Cin, int Cout, int planes, hipStream_t st) {
   int bm, bn, nblocks;
   pick_wino4_tile(NT, Cout, planes, bm, bn, nblocks);
-  static int env_bm = -1, env_bn = 0;   // dev knob "BMxBN", read once
-  if (env_bm < 0) {
-    env_bm = 0;
+  static int env_bm = 0, env_bn = 0, env_seen = -1;   // dev knob UOC_WINO4_TILE="BMxBN", cached (uoc_reload_env re-reads)
+  if (env_seen != g_env_epoch.load(std::memory_order_acquire)) {
+    env_seen = g_env_epoch.load(std::memory_order_acquire);
+    env_bm = env_bn = 0;
     if (const char *e = getenv("UOC_WINO4_TILE")) {
       int a = 0, b = 0;
       if (sscanf(e, "%dx%d", &a, &b) == 2 && (b == 64 || b == 128)) env_bm = a, env_bn = b;
