@@ -203,15 +203,41 @@ def parity_report(gpu_maps, cpu_npz, network=None, network_crop=None, device=Non
     # this over all 1024 frames; here it is re-checked on the frames of this run.
     from oracle import margins as MG
     near = MG.load_bench_margins(ROOT, frames=range(n))
-    beyond = 0
+    beyond, beyond_px = 0, {}
     for i in range(n):
         if mism[i] and i in near:
             bad = MG.label_changes(want[i], gpu_maps[i])
-            beyond += int((MG.lookup_margins(near[i]["idxF"], near[i]["valF"], bad) > MG.TAU).sum())
+            over = bad[MG.lookup_margins(near[i]["idxF"], near[i]["valF"], bad) > MG.TAU]
+            beyond += int(len(over))
+            if len(over):
+                beyond_px[i] = over
         elif mism[i]:
             beyond += mism[i]
+            beyond_px[i] = MG.label_changes(want[i], gpu_maps[i])
+    # pixels beyond the margin: the FROZEN perturbation protocol of tests/test_headline_parity_gpu.py (oracle/margins.py:
+    # PERTURB_RUNS seeded runs of the oracle at 1x the measured embedding error, oracle embeddings only).  What it explains is
+    # "unresolved by the oracle"; a frame that needs the escalation (more runs / 2x / 4x eps) is REPORTED as escalated;
+    # what even that does not cover is unexplained.  Bounded: at most two frames (~1 min of oracle each).
+    escalated, unexplained = [], 0
+    if beyond_px:
+        from oracle import backbone_oracle as BO
+        from unseenobjectclustering_amd import runner as _runner, synth as _synth
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in _synth.calibrated_state_dict().items()}
+        cpu_net = lambda image, label, depth: BO.segnet_forward(sd, image, depth)
+        for i in sorted(beyond_px)[:2]:
+            img, dep = (torch.from_numpy(a) for a in _palette(i))
+            changed, base, info, _ = MG.unresolved_pixels(img, dep, cpu_net, _runner.frame_rng_seed(i), 2.5e-6)
+            px = beyond_px[i]
+            ok = np.isin(px, changed) | (info["marginF"].reshape(-1)[px] <= MG.TAU)
+            if not ok.all():
+                extra, _, _ = MG.escalated_pixels(img, dep, cpu_net, _runner.frame_rng_seed(i), base, 2.5e-6, px[~ok])
+                escalated.append(i)
+                unexplained += int((~ok & ~np.isin(px, extra)).sum())
+        unexplained += sum(len(beyond_px[i]) for i in sorted(beyond_px)[2:])
     rep = {"frames": n, "label_agreement_min": round(min(agree), 6) if agree else None,
            "mismatched_pixels": mism, "mismatches_beyond_margin": beyond, "margin_tau": MG.TAU,
+           "escalated_frames": escalated, "unexplained_pixels": unexplained,
+           "perturbation_protocol": f"{MG.PERTURB_RUNS} seeded oracle runs at 1x eps = 2.5e-6, oracle embeddings only",
            "exact_up_to_permutation": exact if n else None,
            "against": "oracle/ (torch-CPU restatement pinned to the reference by tests/golden), same frames/seeds/weights"}
     embed_dir = os.path.join(os.path.dirname(cpu_npz), "embed")
@@ -226,8 +252,9 @@ def parity_report(gpu_maps, cpu_npz, network=None, network_crop=None, device=Non
     for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "bench_oracle", "frames_*.npz"))):
         zf = np.load(path)
         if int(zf["first"]) < n:
-            for i in range(len(zf["final"])):
-                fixture[int(zf["first"]) + i] = zf["final"][i]
+            first, fin = int(zf["first"]), zf["final"]       # an NpzFile decompresses the whole array on every access
+            for i in range(min(len(fin), n - first)):
+                fixture[first + i] = fin[i].copy()
     given_bad_fix, oracle_vs_fix = [], []
     for g in range(n):
         if not os.path.exists(os.path.join(embed_dir, f"f2_{g}.npy")):
@@ -313,16 +340,25 @@ class SmiSampler(threading.Thread):
 
 
 def frame_roofline(rois, sec_per_frame):
-    """Whole-frame position against both rooflines from SURVEY.md 8(d)'s ALGORITHMIC per-frame work (the
-    reference's formulation: farthest-point sampling re-reads X every step, convolutions are direct):
-    clustering 8.98 GB + 1.43 GB per ROI; backbone 424.4 GFLOP + 69.3 per ROI, clustering 86.5 GFLOP + 14.1 per ROI."""
+    """Whole-frame position against both rooflines.  Algorithmic work per frame from SURVEY.md 8(d) (the reference's
+    formulation: farthest-point sampling re-reads X every step, convolutions are direct): clustering 8.98 GB + 1.43 GB per
+    ROI; backbone 424.4 GFLOP + 69.3 per ROI, clustering 86.5 GFLOP + 14.1 per ROI.
+    `mfma_frac` is the EXECUTED-flop fraction (a fraction of a roofline cannot exceed 1): the Winograd-eligible
+    convolutions (2 x 208.1 GFLOP of stage 1, 68.0 of a ROI's 69.3) execute 36/144 of their direct flops on the matrix
+    pipe — real outputs only, tile padding is waste, not work; everything else executes what it counts.  The algorithmic
+    rate (direct-convolution flops over the same time; > 1 is Winograd's saving, not speed) is reported next to it."""
     gb = 8.98 + 1.43 * rois
     gflop = 424.4 + 86.5 + (69.3 + 14.1) * rois
+    wino = 416.2 + 68.0 * rois                     # direct-form flops of the layers that run as F(4x4,3x3)
+    executed = gflop - 0.75 * wino
     return {"rois_per_frame": round(rois, 2), "algorithmic_gb": round(gb, 2), "algorithmic_gflop": round(gflop, 1),
+            "executed_gflop": round(executed, 1),
             "hbm_frac": round(gb / sec_per_frame / PEAK_HBM_GBS, 4),
-            "mfma_frac": round(gflop / 1e3 / sec_per_frame / PEAK_FP32_TFLOPS, 4),
-            "note": "algorithmic bytes/flops of SURVEY 8(d) per frame over the measured frame time; the on-chip "
-                    "sampling kernel and Winograd move/execute less than the algorithmic amounts"}
+            "mfma_frac": round(executed / 1e3 / sec_per_frame / PEAK_FP32_TFLOPS, 4),
+            "algorithmic_mfma_frac": round(gflop / 1e3 / sec_per_frame / PEAK_FP32_TFLOPS, 4),
+            "note": "algorithmic bytes/flops of SURVEY 8(d) per frame over the measured frame time; mfma_frac = flops the "
+                    "matrix pipe executes for real outputs (Winograd layers: 36/144 of the direct form); the on-chip sampling "
+                    "kernel moves less than the algorithmic bytes"}
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -357,7 +393,7 @@ def compact_line(full, full_path):
                                 "scaling", "vs_baseline", "dtype", "data")}
     out["config"] = full["config"]
     roof = full.get("roofline")
-    out["roofline"] = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
+    out["roofline"] = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us",
                                    "gpu_time_share", "algorithmic_tflops", "matrix_pipe_tflops", "matrix_pipe_frac"))
     cpu = full.get("cpu_baseline")
     out["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "host_cores", "cpu_model", "kind", "sample"))
@@ -365,24 +401,37 @@ def compact_line(full, full_path):
         out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:110]
     par = full.get("parity")
     out["parity"] = _pick(par, ("frames", "embed_max_err", "stage1_exact", "mismatched_pixels", "mismatches_beyond_margin",
+                                "escalated_frames", "unexplained_pixels",
                                 "given_oracle_embeddings_mismatched_pixels", "given_oracle_embeddings_beyond_margin",
                                 "given_oracle_embeddings_mismatched_pixels_vs_fixture_oracle"))
+    for k in ("mismatched_pixels", "given_oracle_embeddings_mismatched_pixels", "given_oracle_embeddings_mismatched_pixels_vs_fixture_oracle"):
+        v = (out["parity"] or {}).get(k)         # per-frame lists grow with --cpu-frames: count / max / first 8 beyond that
+        if isinstance(v, list) and len(v) > 8:
+            out["parity"][k] = {"frames": len(v), "sum": int(sum(v)), "max": int(max(v)), "first": v[:8]}
     lat = full.get("latency")
     out["latency"] = _pick(lat, ("ms_per_frame", "frames_per_s"))
     sus = full.get("sustained")
     out["sustained_frames_per_s"] = sus["frames_per_s"] if sus else None
     out["pcie_inclusive_frames_per_s"] = full.get("pcie_inclusive_frames_per_s")
     fr = full.get("frame_roofline")
-    out["frame_roofline"] = _pick(fr, ("rois_per_frame", "hbm_frac", "mfma_frac"))
-    out["per_rank"] = [_pick(r, ("frames", "compute_s", "gather_s")) for r in (full.get("per_rank") or [])][:8]
+    out["frame_roofline"] = _pick(fr, ("rois_per_frame", "hbm_frac", "mfma_frac", "algorithmic_mfma_frac"))
+    out["per_rank"] = [_pick(r, ("frames", "compute_s", "gather_s", "host_cpu_s")) for r in (full.get("per_rank") or [])][:8]
     out["kernel_time_share"] = {k["kernel"]: k["gpu_time_share"] for k in (full.get("kernels") or [])[:6]}
     out["full"] = full_path
-    n = len(json.dumps(out, separators=(",", ":")))
-    if n > MAX_LINE_BYTES:                      # never again: drop the optional parts rather than lose the record
-        for k in ("kernel_time_share", "per_rank", "frame_roofline"):
-            out.pop(k, None)
-        out["config"] = _pick(out["config"], ("workload", "total_frames", "frames_per_gpu", "streams_per_gpu", "frames_per_launch"))
-        out["config"]["workload"] = out["config"]["workload"][:160]
+    size = lambda: len(json.dumps(out, separators=(",", ":")))
+    # never again: drop / shorten the optional parts, most expendable first, RE-MEASURING after each step, rather than lose
+    # the record to the driver's output tail
+    steps = [lambda: out.pop("kernel_time_share", None), lambda: out.pop("per_rank", None), lambda: out.pop("frame_roofline", None),
+             lambda: out.__setitem__("config", _pick(out.get("config"), ("workload", "total_frames", "frames_per_gpu", "streams_per_gpu",
+                                                                         "frames_per_launch")) or {}),
+             lambda: out["config"].__setitem__("workload", str(out["config"].get("workload", ""))[:160]),
+             lambda: out.__setitem__("parity", _pick(out.get("parity"), ("frames", "embed_max_err", "mismatches_beyond_margin", "escalated_frames"))),
+             lambda: (out.get("cpu_baseline") or {}).pop("sample", None), lambda: (out.get("cpu_baseline") or {}).pop("cpu_model", None),
+             lambda: out.pop("latency", None), lambda: out.pop("parity", None), lambda: out.pop("config", None) or out.__setitem__("config", {})]
+    for step in steps:
+        if size() <= MAX_LINE_BYTES:
+            break
+        step()
     return out
 
 
@@ -675,6 +724,7 @@ def main():
             ach = dom["flops"] / sec / 1e12
             roof = {"kernel": dom["kernel"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                    "algorithmic_bytes": round(dom["bytes"] / dom["launches"]),   # per launch, like `traffic` (PMC): the ratio is the re-read factor
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2),
                     "frames_per_launch": max(1, args.frames_per_launch),
                     "by_shape": [d for d in by_shape if d["kernel"] == dom["kernel"]]}
@@ -706,6 +756,7 @@ def main():
             ach = dom["bytes"] / sec / 1e9
             roof = {"kernel": dom["kernel"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes": round(dom["bytes"] / dom["launches"]),
                     "avg_launch_us": round(1e3 * dom["total_ms"] / dom["launches"], 2)}
 
     if roof is not None:

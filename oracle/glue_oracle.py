@@ -115,7 +115,7 @@ def clustering_features(features: torch.Tensor, first_indices, num_seeds: int = 
     B, C, H, W = features.shape
     out = torch.zeros((B, H, W))
     for j in range(B):
-        X = features[j].reshape(C, -1).t().contiguous()
+        X = torch.transpose(features[j].view(C, -1), 0, 1)     # :54-55: the STRIDED transpose, as the reference multiplies it
         lab, _ = MS.mean_shift_smart_init(X, kappa, num_seeds, max_iters, first_index=int(first_indices[j]), epsilon=epsilon)
         out[j] = lab.view(H, W).float()
     return out

@@ -24,12 +24,15 @@ import torch.nn.functional as F
 from . import glue_oracle as GO
 from . import mean_shift_oracle as MS
 
-# Perturbation bound used by the parity tests (DESIGN.md section 5 derives it):
-#   |delta margin| <= 2 * 0.5 * (|dx| + |dz|)  with  |dx| = L2 error of a pixel's embedding, |dz| = L2 error of a seed
-# measured on the bench frames (tests/test_headline_parity_gpu.py::test_tau_is_the_measured_perturbation states the live
-# values, profiles/r04_parity_tau.json): |dx| = 2.0e-6 .. 2.3e-6; |dz| of 99 % of the seeds 2e-7 .. 9e-7 (a well supported
-# seed CONTRACTS the error), sparsely supported seeds up to 3.9e-4 (largest of 2 400 seeds) — and the largest margin of a
-# pixel that actually differs over 1 024 frames is 3.9e-4 as well (profiles/r04_parity_margins.json).
+# Margin threshold of the parity tests — an EMPIRICAL threshold with a stated headroom, not a derived constant.
+#   A margin between seeds a and b moves by at most |dx| + (|dz_a| + |dz_b|) / 2 when the pixel's embedding moves by dx and the
+#   seeds by dz (unit vectors, L2 norms).  Measured on the bench frames (test_tau_is_the_measured_perturbation,
+#   profiles/r04_parity_tau.json): |dx| = 2.0e-6 .. 2.3e-6; |dz| of 99 % of the seeds 2e-7 .. 9e-7 (a well supported seed
+#   CONTRACTS the error); the largest movement of a sparsely supported seed among 2 400 seeds: 3.9e-4.
+#   The largest margin of a pixel that ACTUALLY differs over the 1 024 bench frames: 4.915e-4 (profiles/r04_parity_margins.json)
+#   — TAU sits 1.7 % above it: the bound on |dx| + |dz|(q99) holds with 150x slack and does not constrain TAU, the seed
+#   movements of sparsely supported seeds do.  Because the margin rule alone would admit any NUMBER of near-tie pixels, the
+#   tests keep hard count bounds next to it (worst frame <= 32 pixels, 99th percentile <= 5, smoke <= 4).
 TAU = 5e-4
 TAU_STORE = 2e-3        # sparse fixtures keep every pixel below this
 
@@ -71,7 +74,7 @@ def test_sample_with_margins(image, depth, network, network_crop, rng, epsilon: 
     f1 = network(image, None, depth)
     C, H, W = f1.shape[1:]
     n = H * W
-    X1 = f1[0].reshape(C, -1).t().contiguous()
+    X1 = torch.transpose(f1[0].view(C, -1), 0, 1)          # test_dataset.py:54-55: strided view, as the reference clusters it
     first = rng.randint(0, n)
     lab1, _, parts1 = MS.mean_shift_smart_init(X1, 20.0, 100, 10, first_index=int(first), epsilon=epsilon, return_parts=True)
     out_label = lab1.view(1, H, W).float()
@@ -98,7 +101,7 @@ def test_sample_with_margins(image, depth, network, network_crop, rng, epsilon: 
     marginF = torch.full((H, W), float("inf"))
     X2s, Z2s, cc, ov = [], [], [], []
     for k in range(K):
-        X2 = f2[k].reshape(C, -1).t().contiguous()
+        X2 = torch.transpose(f2[k].view(C, -1), 0, 1)
         lab2, _, p2 = MS.mean_shift_smart_init(X2, 20.0, 100, 10, first_index=int(rng.randint(0, S * S)), epsilon=epsilon,
                                                return_parts=True)
         labels_c[k] = lab2.view(S, S).float()
@@ -160,31 +163,52 @@ def label_changes(base, other) -> np.ndarray:
     return np.nonzero(to_b[a] != b)[0]
 
 
-def unresolved_pixels(image, depth, network, rng_seed: int, eps: float, runs: int = 4, extra_networks=(), need=None,
-                      max_runs: int = 24):
+PERTURB_RUNS = 8        # THE protocol: 8 seeded sign patterns (seeds 1000.. / 2000..) at 1x the measured embedding error, no more
+
+
+def perturbation_run(image, depth, network, rng_seed: int, base, eps: float, index: int) -> np.ndarray:
+    """Final-map pixels whose label differs from `base` when the oracle's whole path runs on embeddings perturbed by `eps`
+    per component with the sign pattern number `index` (stage 1: seed 1000 + index, crops: 2000 + index)."""
+    o, r = GO.test_sample(image, depth, perturbed_network(network, eps, 1000 + index), perturbed_network(network, eps, 2000 + index),
+                          np.random.RandomState(rng_seed))
+    return label_changes(base, (r if r is not None else o)[0].numpy())
+
+
+def unresolved_pixels(image, depth, network, rng_seed: int, eps: float, runs: int = PERTURB_RUNS, run_many=None):
     """Final-map pixels whose label the oracle's own arithmetic does not resolve at embedding error `eps`: the union, over
-    seeded perturbations (and over `extra_networks`: pairs (network, network_crop) of other embedding sources within the
-    tolerance, e.g. the HIP networks), of the pixels whose label differs from the unperturbed oracle run's.
-    A seed between two modes falls to either side with some probability per run (bench frame 351: the 7th run), so the
-    evidence is constructive: at least `runs` perturbations, then more (up to `max_runs`) while pixels of `need` (flat
-    indices) are still uncovered; runs 0-7 perturb by `eps`, runs 8-15 by 2 eps, later ones by 4 eps (with eps = 2.5e-6
-    still 100x below the 1e-3 embedding tolerance north_star states).
-    Returns (flat indices, base final map, base info, perturbed runs used)."""
+    EXACTLY `runs` seeded perturbations of the ORACLE's embeddings (no other embedding source, no escalation), of the pixels
+    whose label differs from the unperturbed oracle run's.  Frozen in round 5 (VERDICT r4 / ADVICE): until then the runs
+    continued — up to 24, the late ones at 2x / 4x eps, plus a run on the HIP networks' embeddings — until the pixels of
+    interest were covered, which is a search for a witness, not a bound.
+    `run_many(base, [i, ...]) -> [changed_i, ...]`: optional executor of perturbation_run(…, index=i) for the given indices
+    (e.g. a process pool: the runs are independent); it must not choose anything — which runs, seeds and eps is fixed here.
+    Returns (flat indices, base final map, base info, per-run change sets)."""
     out, refined, info = test_sample_with_margins(image, depth, network, network, np.random.RandomState(rng_seed))
     base = (refined if refined is not None else out)[0].numpy()
+    if run_many is not None:
+        per_run = list(run_many(base, list(range(runs))))
+        assert len(per_run) == runs
+    else:
+        per_run = [perturbation_run(image, depth, network, rng_seed, base, eps, i) for i in range(runs)]
     changed = np.zeros(0, np.int64)
+    for c in per_run:
+        changed = np.union1d(changed, c)
+    return changed, base, info, per_run
 
-    def one(n1, n2):
-        o, r = GO.test_sample(image, depth, n1, n2, np.random.RandomState(rng_seed))
-        return label_changes(base, (r if r is not None else o)[0].numpy())
-    for n1, n2 in extra_networks:
-        changed = np.union1d(changed, one(n1, n2))
-    used = 0
-    while used < runs or (need is not None and used < max_runs and not np.isin(need, changed).all()):
-        e = eps * (1 if used < 8 else 2 if used < 16 else 4)
-        changed = np.union1d(changed, one(perturbed_network(network, e, 1000 + used), perturbed_network(network, e, 2000 + used)))
+
+def escalated_pixels(image, depth, network, rng_seed: int, base, eps: float, need: np.ndarray, first: int = PERTURB_RUNS,
+                     last: int = 24):
+    """OUTSIDE the protocol, for the report only: further perturbation runs (indices first..last-1; 8-15 at 2x eps, 16-23 at
+    4x) until the pixels `need` are covered.  A frame that needs this is reported as `escalated` by the tests and by
+    bench.py, never silently passed.  Returns (flat indices covered by the extra runs, runs used, largest eps factor)."""
+    changed, used, factor = np.zeros(0, np.int64), 0, 1
+    for i in range(first, last):
+        if np.isin(need, changed).all():
+            break
+        factor = 1 if i < 8 else 2 if i < 16 else 4
+        changed = np.union1d(changed, perturbation_run(image, depth, network, rng_seed, base, eps * factor, i))
         used += 1
-    return changed, base, info, used
+    return changed, used, factor
 
 
 # ---- the committed near-tie sets of the benchmark frames (tests/golden/bench_margins, make_bench_margins.py) ------------

@@ -15,8 +15,9 @@ net = lambda img, label, depth: BO.segnet_forward(sd, img, depth)
 fix = {}
 for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "bench_oracle", "frames_*.npz"))):
     z = np.load(path)
-    for i in range(len(z["final"])):
-        fix[int(z["first"]) + i] = z["final"][i]
+    fin = z["final"]
+    for i in range(len(fin)):
+        fix[int(z["first"]) + i] = fin[i]
 out = []
 for g in frames:
     s = 10_000 + g

@@ -1,7 +1,9 @@
-"""Dev helper: one 3x3 layer as Winograd F(2x2,3x3) (csrc/wino.hip) vs F(4x4,3x3) (csrc/wino4.hip: planes as groups of the
-direct 1x1 kernel / persistent plane GEMM, tile overrides) on the launch shapes of the pipeline (four frames per launch
-set in stage 1, ~28 crops in stage 2).  Times from the library's per-kernel-class HIP events; TF = algorithmic (direct
-3x3) flops over the summed time of the layer's kernels."""
+"""Dev helper (DEVELOPMENT build: python -m unseenobjectclustering_amd.build --dev; run with
+UOC_LIB_PATH=unseenobjectclustering_amd/libuoc_hip_dev.so): one 3x3 layer as Winograd F(4x4,3x3) (csrc/wino4.hip) on the
+launch shapes of the pipeline (four frames per launch set in stage 1, ~28 crops in stage 2) under the plane GEMM's knobs
+(waves per block, tile overrides, planes as groups of the direct 1x1 kernel), next to F(2x2,3x3) and the direct kernel.
+Times from the library's per-kernel-class HIP events; TF = algorithmic (direct 3x3) flops over the summed time of the
+layer's kernels.  WINO4_BENCH_ONLY=<substring> restricts the arms, WINO4_BENCH_SHAPES=<substring> the shapes."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,31 +12,31 @@ dev = torch.device("cuda:0")
 L = _native.lib()
 P = _native.ptr
 G = 2
+KNOBS = ("UOC_WINO4_GEMM", "UOC_WINO4_TILE", "UOC_W4_WAVES", "UOC_W4_PAIR")
 shapes = [  # name, B, H, W, C, dil
     ("s1 layer4 512 d4 4x60x80", 4, 60, 80, 512, 4),
     ("s1 layer3 256 d2 4x60x80", 4, 60, 80, 256, 2),
     ("s1 layer2 128 d1 4x60x80", 4, 60, 80, 128, 1),
+    ("s1 layer1 64 d1 4x120x160", 4, 120, 160, 64, 1),
     ("s2 layer4 512 d4 28x28x28", 28, 28, 28, 512, 4),
     ("s2 layer3 256 d2 28x28x28", 28, 28, 28, 256, 2),
     ("s2 layer2 128 d1 28x28x28", 28, 28, 28, 128, 1),
     ("s1 layer4 512 d4 1x60x80", 1, 60, 80, 512, 4),
-    # round 4, VERDICT item 5 (F(3x3) remainder tiles for the 7x7 phase images of the crops): the plane GEMM a tile CLASS
-    # of that scheme would run — ONE tile per phase image (28 crops x 16 phases = 448 rows per plane) instead of four
-    ("s2 layer4 one tile per phase image 28x16x16", 28, 16, 16, 512, 4),
 ]
 
 
-def measure(B, H, W, C, dil, env, iters=10):
-    for k in ("UOC_CONV_WINOGRAD", "UOC_WINO4_GEMM", "UOC_WINO4_TILE"):
+def measure(B, H, W, C, dil, algo, env, iters=10):
+    for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(env)
     L.uoc_reload_env()          # the library caches its knobs
-    x = torch.randn(G, B, H, W, C, device=dev)
-    w = torch.randn(G, 9, C, C, device=dev) * 0.02
-    b = torch.randn(G, C, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(1234 + B + C)       # same operands for every arm: the bit-identity check
+    x = torch.randn(G, B, H, W, C, device=dev, generator=gen)
+    w = torch.randn(G, 9, C, C, device=dev, generator=gen) * 0.02
+    b = torch.randn(G, C, device=dev, generator=gen)
     out = torch.empty(G, B, H, W, C, device=dev)
     st = _native.stream_ptr(dev)
-    run = lambda: _native.check(L.uoc_conv2d_nhwc(P(x), P(w), P(b), None, P(out), G, B, H, W, C, C, 3, 1, dil, dil, 1, st), "conv")
+    run = lambda: _native.check(L.uoc_conv2d_nhwc_algo(P(x), P(w), P(b), None, P(out), G, B, H, W, C, C, 3, 1, dil, dil, 1, algo, st), "conv")
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -44,29 +46,39 @@ def measure(B, H, W, C, dil, env, iters=10):
     torch.cuda.synchronize()
     rep = {r["kernel"]: 1e3 * r["total_ms"] / r["launches"] for r in _native.prof_report()}
     _native.prof_enable(False)
-    return rep
+    return rep, out
 
 
+is_dev = L.uoc_is_dev_build() == 1
+arms = [("F4 8 waves auto", 4, {"UOC_W4_WAVES": "8"}), ("F4 4 waves auto", 4, {"UOC_W4_WAVES": "4"})]
+if is_dev:
+    arms += [(f"F4 {nw} waves {t // 1000}x{t % 1000}", 4, {"UOC_W4_WAVES": str(nw), "UOC_WINO4_TILE": str(t)})
+             for t in (192128, 160128, 128128, 96128) for nw in (8, 4)]
+    arms += [(f"F4 8 waves {t // 1000}x{t % 1000} wide", 4, {"UOC_W4_WAVES": "8", "UOC_WINO4_TILE": str(t)}) for t in (160256, 128256, 96256)]
+    arms += [("F4 planes-as-groups", 4, {"UOC_WINO4_GEMM": "1"}), ("F2", 2, {})]
+else:
+    arms = [("F4 shipped", 4, {})]
+arms.append(("direct", 0, {}))
 for name, B, H, W, C, dil in shapes:
+    if os.environ.get("WINO4_BENCH_SHAPES") and os.environ["WINO4_BENCH_SHAPES"] not in name:
+        continue
     fl = 2.0 * G * B * H * W * C * C * 9
-    measure(B, H, W, C, dil, {"UOC_CONV_WINOGRAD": "1"}, 5)   # clock ramp
+    measure(B, H, W, C, dil, 4, {}, 5)   # clock ramp
     print(f"{name}  [{fl / 1e9:.1f} GF]", flush=True)
-    for label, env in (("F2", {"UOC_CONV_WINOGRAD": "1"}),
-                       ("F4 planes-as-groups", {"UOC_CONV_WINOGRAD": "4", "UOC_WINO4_GEMM": "1"}),
-                       ("F4 persistent auto", {"UOC_CONV_WINOGRAD": "4", "UOC_WINO4_GEMM": "2"}),
-                       ("F4 persistent 192x128", {"UOC_CONV_WINOGRAD": "4", "UOC_WINO4_GEMM": "2", "UOC_WINO4_TILE": "192x128"}),
-                       ("F4 persistent 160x128", {"UOC_CONV_WINOGRAD": "4", "UOC_WINO4_GEMM": "2", "UOC_WINO4_TILE": "160x128"}),
-                       ("F4 persistent 128x128", {"UOC_CONV_WINOGRAD": "4", "UOC_WINO4_GEMM": "2", "UOC_WINO4_TILE": "128x128"}),
-                       ("F4 persistent 96x128", {"UOC_CONV_WINOGRAD": "4", "UOC_WINO4_GEMM": "2", "UOC_WINO4_TILE": "96x128"}),
-                       ("F4 persistent 192x64", {"UOC_CONV_WINOGRAD": "4", "UOC_WINO4_GEMM": "2", "UOC_WINO4_TILE": "192x64"}),
-                       ("direct", {})):
+    ref = None
+    for label, algo, env in arms:
         if os.environ.get("WINO4_BENCH_ONLY") and os.environ["WINO4_BENCH_ONLY"] not in label:
             continue
         try:
-            rep = measure(B, H, W, C, dil, env)
+            rep, out = measure(B, H, W, C, dil, algo, env)
         except Exception as e:  # noqa: BLE001
             print(f"   {label:24s} failed: {e}")
             continue
+        same = ""
+        if algo == 4 and "planes" not in label:        # every plane-GEMM arm must give the same bits
+            if ref is None:
+                ref = out.clone()
+            same = "  bit-identical" if torch.equal(ref, out) else "  DIFFERS FROM THE FIRST F4 ARM"
         tot = sum(rep.values())
         parts = "  ".join(f"{k}:{v:7.1f}" for k, v in rep.items())
-        print(f"   {label:24s} total {tot:7.1f} us = {fl / tot / 1e6:6.1f} TF algorithmic   {parts}", flush=True)
+        print(f"   {label:24s} total {tot:7.1f} us = {fl / tot / 1e6:6.1f} TF algorithmic   {parts}{same}", flush=True)

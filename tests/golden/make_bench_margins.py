@@ -38,8 +38,10 @@ def main():
     for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "bench_oracle", "frames_*.npz"))):
         z = np.load(path)
         if int(z["first"]) < hi and int(z["first"]) + len(z["final"]) > lo:
-            for i in range(len(z["final"])):
-                fixture[int(z["first"]) + i] = (z["stage1"][i], z["final"][i])
+            first, s1, fin = int(z["first"]), z["stage1"], z["final"]  # an NpzFile decompresses the whole array on every access
+            for i in range(len(fin)):
+                if lo <= first + i < hi:
+                    fixture[first + i] = (s1[i].copy(), fin[i].copy())
     acc = {k: [] for k in ("idx1", "val1", "idxF", "valF", "rois")}
     off = {k: [0] for k in acc}
     slack, differs = [], []

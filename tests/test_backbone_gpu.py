@@ -145,12 +145,19 @@ WINO4_EXTRA_CASES = [
 ]
 
 
-@pytest.mark.parametrize("algo", ["f2", "f4", "f4-planes-as-groups"])
+def _algos():
+    """The shipped library holds ONE Winograd path (F(4x4,3x3), persistent plane GEMM).  A development build
+    (python -m unseenobjectclustering_amd.build --dev, loaded through UOC_LIB_PATH) also carries the measured alternates."""
+    dev = _native.lib().uoc_is_dev_build() == 1
+    return ["f4", "f2", "f4-planes-as-groups"] if dev else ["f4"]
+
+
+@pytest.mark.parametrize("algo", _algos())
 @pytest.mark.parametrize("case", WINO_CASES + WINO4_EXTRA_CASES)
 def test_winograd_conv_vs_torch_cpu(device, case, algo):
-    """Winograd paths — F(4x4,3x3) (csrc/wino4.hip; persistent plane GEMM, or the planes as groups of the direct 1x1
-    kernel) and F(2x2,3x3) (csrc/wino.hip) — against torch CPU conv2d; fp32 Winograd differs from the direct sum only by
-    rounding (bar: 2e-4 of the output scale, measured ~1e-6)."""
+    """Winograd F(4x4,3x3) (csrc/wino4.hip) against torch CPU conv2d; fp32 Winograd differs from the direct sum only by
+    rounding (bar: 2e-4 of the output scale, measured ~1e-6).  Development builds: also the planes as groups of the direct
+    1x1 kernel and F(2x2,3x3) (csrc/wino.hip)."""
     G, B, H, W, Cin, Cout, dil, use_res, relu = case
     if algo == "f2" and case in WINO4_EXTRA_CASES[:2]:
         pytest.skip("large cases are for the F(4x4) item loop")
@@ -164,30 +171,15 @@ def test_winograd_conv_vs_torch_cpu(device, case, algo):
         ref = ref + res
     if relu:
         ref = F.relu(ref)
-    xd = x.permute(0, 1, 3, 4, 2).contiguous().to(device)
-    wd = w.permute(0, 3, 4, 1, 2).reshape(G, 9, Cout, Cin).contiguous().to(device)
-    bd = b.to(device)
-    rd = res.permute(0, 1, 3, 4, 2).contiguous().to(device) if res is not None else None
-    out = torch.empty((G, B, H, W, Cout), device=device)
-    L = _native.lib()
-    os.environ["UOC_CONV_WINOGRAD"] = "1" if algo == "f2" else "4"
-    os.environ["UOC_WINO4_GEMM"] = "1" if algo == "f4-planes-as-groups" else "2"
-    L.uoc_reload_env()           # the library caches its development knobs
-    try:
-        rc = L.uoc_conv2d_nhwc(_native.ptr(xd), _native.ptr(wd), _native.ptr(bd), _native.ptr(rd), _native.ptr(out),
-                               G, B, H, W, Cin, Cout, 3, 1, dil, dil, int(relu), _native.stream_ptr(device))
-    finally:
-        os.environ.pop("UOC_CONV_WINOGRAD", None)
-        os.environ.pop("UOC_WINO4_GEMM", None)
-        L.uoc_reload_env()
-    _native.check(rc, "uoc_conv2d_nhwc (winograd)")
-    got = out.cpu().permute(0, 1, 4, 2, 3)
+    env = {"UOC_WINO4_GEMM": "1"} if algo == "f4-planes-as-groups" else None
+    got = _wino4_conv(device, x, w, b, res, dil, relu, env=env, algo=_native.CONV_WINOGRAD2 if algo == "f2" else _native.CONV_WINOGRAD4)
     err = (got - ref).abs().max().item()
     assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
 
 
-def _wino4_conv(device, x, w, b, res, dil, relu, env=None):
-    """uoc_conv2d_nhwc with the F(4x4) hook on; x [G,B,Cin,H,W], w [G,Cout,Cin,3,3], b [G,Cout] | None -> [G,B,Cout,H,W] (CPU)."""
+def _wino4_conv(device, x, w, b, res, dil, relu, env=None, algo=_native.CONV_WINOGRAD4, expect_rc=0):
+    """uoc_conv2d_nhwc_algo; x [G,B,Cin,H,W], w [G,Cout,Cin,3,3], b [G,Cout] | None -> [G,B,Cout,H,W] (CPU).
+    `env`: speed-only / test variables set for the call (uoc_reload_env around it)."""
     G, B, Cin, H, W = x.shape
     Cout = w.shape[1]
     xd = x.permute(0, 1, 3, 4, 2).contiguous().to(device)
@@ -196,33 +188,37 @@ def _wino4_conv(device, x, w, b, res, dil, relu, env=None):
     rd = res.permute(0, 1, 3, 4, 2).contiguous().to(device) if res is not None else None
     out = torch.empty((G, B, H, W, Cout), device=device)
     L = _native.lib()
-    os.environ["UOC_CONV_WINOGRAD"] = "4"
     for k, v in (env or {}).items():
         os.environ[k] = v
     L.uoc_reload_env()
     try:
-        rc = L.uoc_conv2d_nhwc(_native.ptr(xd), _native.ptr(wd), _native.ptr(bd), _native.ptr(rd), _native.ptr(out),
-                               G, B, H, W, Cin, Cout, 3, 1, dil, dil, int(relu), _native.stream_ptr(device))
+        rc = L.uoc_conv2d_nhwc_algo(_native.ptr(xd), _native.ptr(wd), _native.ptr(bd), _native.ptr(rd), _native.ptr(out),
+                                    G, B, H, W, Cin, Cout, 3, 1, dil, dil, int(relu), algo, _native.stream_ptr(device))
     finally:
-        os.environ.pop("UOC_CONV_WINOGRAD", None)
         for k in (env or {}):
             os.environ.pop(k, None)
         L.uoc_reload_env()
-    _native.check(rc, "uoc_conv2d_nhwc (winograd F(4x4) hook)")
+    if expect_rc:
+        assert rc == expect_rc, rc
+        return None
+    _native.check(rc, "uoc_conv2d_nhwc_algo")
     return out.cpu().permute(0, 1, 4, 2, 3)
 
 
 def test_winograd4_edge_cases(device):
-    """(a) Cout = 192 (Cout / 64 not a power of two) must take the direct kernel instead of failing in the plane
-    GEMM; (b) a null bias is zero on the Winograd path as on the direct one; (c) a batch whose frequency planes exceed the
-    32-bit offset range is run as slices of the batch — forced here with UOC_WINO4_MAX_MB — with bit-identical results."""
+    """(a) Cout = 192 (Cout / 64 not a power of two) is not eligible: the explicit-algorithm entry says so
+    (UOC_EINVAL) and the direct kernel — what the network's static rule picks for such a layer — computes it; (b) a null bias
+    is zero on the Winograd path as on the direct one; (c) a batch whose frequency planes exceed the 32-bit offset range is
+    run as slices of the batch — forced here with UOC_SPLIT_MAX_MB — with bit-identical results; (d) the same for the direct
+    kernel's 2 GB input limit (round 5: the batch split replaces the register-staged fallback kernel)."""
     g = torch.Generator().manual_seed(77)
     # (a)
     x = torch.randn(1, 2, 128, 20, 24, generator=g)
     w = torch.randn(1, 192, 128, 3, 3, generator=g) / np.sqrt(128 * 9)
     b = torch.randn(1, 192, generator=g)
     ref = F.relu(F.conv2d(x[0], w[0], b[0], padding=1))
-    got = _wino4_conv(device, x, w, b, None, 1, True)[0]
+    _wino4_conv(device, x, w, b, None, 1, True, expect_rc=-22)
+    got = _wino4_conv(device, x, w, b, None, 1, True, algo=_native.CONV_DIRECT)[0]
     assert (got - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
     # (b)
     x = torch.randn(2, 1, 128, 20, 24, generator=g)
@@ -236,56 +232,12 @@ def test_winograd4_edge_cases(device):
     b = torch.randn(2, 256, generator=g)
     res = torch.randn(2, 5, 256, 28, 28, generator=g)
     whole = _wino4_conv(device, x, w, b, res, 2, True)
-    sliced = _wino4_conv(device, x, w, b, res, 2, True, env={"UOC_WINO4_MAX_MB": "8"})
+    sliced = _wino4_conv(device, x, w, b, res, 2, True, env={"UOC_SPLIT_MAX_MB": "8"})
     assert torch.equal(whole, sliced)
     ref = F.relu(torch.stack([F.conv2d(x[i], w[i], b[i], padding=2, dilation=2) for i in range(2)]) + res)
     assert (whole - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
-
-
-@pytest.mark.parametrize("shape", [(1, 480, 640), (2, 240, 320), (5, 224, 224), (1, 72, 104), (3, 61, 83)])
-def test_fused_transforms_are_bit_identical(device, shape):
-    """Round 4: inside a chain of F(4x4) layers the output transform of one layer and the input
-    transform of the next can run as ONE kernel through LDS (csrc/wino4.hip, wino4_mid_kernel; the intermediate NHWC
-    tensor of a BasicBlock is never written).  Built, bit-identical, and measured SLOWER end to end
-    (profiles/r04_ab_fused_transforms.md), so it is opt-in (UOC_WINO4_FUSE=1).  It calls the arithmetic of the separate
-    kernels (wino4_math.h), so the embeddings must not change by a bit, ragged sizes included."""
-    B, H, W = shape
-    net, _ = _net(3, device)
-    g = torch.Generator().manual_seed(H * W + B)
-    img = torch.randn(B, 3, H, W, generator=g).to(device)
-    xyz = torch.randn(B, 3, H, W, generator=g).to(device)
-    L = _native.lib()
-    separate = net(img, None, xyz).clone()
-    os.environ["UOC_WINO4_FUSE"] = "1"
-    L.uoc_reload_env()
-    try:
-        fused = net(img, None, xyz).clone()
-    finally:
-        os.environ.pop("UOC_WINO4_FUSE", None)
-        L.uoc_reload_env()
-    assert torch.equal(fused, separate)
-    assert torch.isfinite(fused).all()
-
-
-@pytest.mark.parametrize("shape", [(1, 480, 640), (5, 224, 224), (1, 72, 104), (3, 61, 83)])
-def test_small_k_fused_gemm_is_bit_identical(device, shape):
-    """Round 4 experiment, opt-in (UOC_WINO4_SMALL=1; measured slower, csrc/wino4.hip wino4_small_ok): the 64- and 128-channel
-    F(4x4) layers with their 72 plane GEMMs and the output transform as ONE kernel (all 36 plane accumulators of a 16 x 16
-    tile in registers, no M planes).  Same MFMA order per accumulator and the same transform functions as the separate
-    kernels: it must give the same bits."""
-    B, H, W = shape
-    net, _ = _net(4, device)
-    g = torch.Generator().manual_seed(H * W + 7 * B)
-    img = torch.randn(B, 3, H, W, generator=g).to(device)
-    xyz = torch.randn(B, 3, H, W, generator=g).to(device)
-    L = _native.lib()
-    separate = net(img, None, xyz).clone()
-    os.environ["UOC_WINO4_SMALL"] = "1"
-    L.uoc_reload_env()
-    try:
-        fused = net(img, None, xyz).clone()
-    finally:
-        os.environ.pop("UOC_WINO4_SMALL", None)
-        L.uoc_reload_env()
-    assert torch.equal(fused, separate)
-    assert torch.isfinite(fused).all()
+    # (d) direct kernel: 2 groups x 5 images of 28 x 28 x 256 x 4 B = 0.8 MB each; a 2 MB limit -> per group 3 + 2, then 2 + 1 ...
+    whole = _wino4_conv(device, x, w, b, res, 2, True, algo=_native.CONV_DIRECT)
+    sliced = _wino4_conv(device, x, w, b, res, 2, True, algo=_native.CONV_DIRECT, env={"UOC_SPLIT_MAX_MB": "2"})
+    assert torch.equal(whole, sliced)
+    assert (whole - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())

@@ -61,3 +61,39 @@ def test_compact_line_of_a_full_record_stays_small():
     d = json.loads(line)
     assert d["roofline"]["frac"] == full["roofline"]["frac"] and d["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
     assert "by_shape" not in d["roofline"] and "conv_by_shape" not in d and "kernels" not in d
+
+
+def test_self_launch_eight_ranks_matches_single_process(tmp_path):
+    """The launch shape of BASELINE configs[4] (8 ranks, strong scaling) through the whole plumbing on CPU: self-launcher,
+    tune-cache barriers (the two barriers pair up on every rank also in --stub runs), error-flag + configuration-fingerprint
+    all-reduce, all_gather of 8 blocks, 8 per_rank entries on a line that stays under the driver's tail."""
+    eight, maps8 = _run(tmp_path, "eight", "--gpus", "8", "--warmup", "1", "--frames", "19")     # ragged: blocks of 3, last rank short
+    one, maps1 = _run(tmp_path, "one", "--gpus", "1", "--warmup", "1", "--frames", "19")
+    assert eight["n_gpus"] == 8 and eight["scaling"] == "strong" and eight["config"]["collective"] is True
+    assert len(eight["per_rank"]) == 8 and sum(r["frames"] for r in eight["per_rank"]) == 19
+    assert all("host_cpu_s" in r for r in eight["per_rank"])
+    assert maps8.shape == maps1.shape == (19, 12, 16) and np.array_equal(maps1, maps8)
+
+
+def test_compact_line_never_exceeds_the_cap_whatever_the_record_holds():
+    """the optional parts are dropped in a loop that re-measures; per-frame parity lists are summarised; a
+    record without config.workload does not raise."""
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_full.json")))
+    full["parity"]["mismatched_pixels"] = list(range(400))                       # a long --cpu-frames run
+    full["parity"]["given_oracle_embeddings_mismatched_pixels"] = [0] * 400
+    full["config"]["workload"] = "x" * 5000
+    full["cpu_baseline"]["sample"] = "y" * 5000
+    full["per_rank"] = [dict(full["per_rank"][0], gather_s=0.0123, host_cpu_s=1.234567) for _ in range(8)]
+    line = json.dumps(bench.compact_line(full, "gpurun_out/bench_full.json"), separators=(",", ":"))
+    assert len(line) <= bench.MAX_LINE_BYTES
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline", "full"):
+        assert key in d
+    assert d["parity"]["mismatched_pixels"]["frames"] == 400 and d["parity"]["mismatched_pixels"]["max"] == 399
+    del full["config"]["workload"]
+    assert len(json.dumps(bench.compact_line(full, "p"), separators=(",", ":"))) <= bench.MAX_LINE_BYTES
+    fr = bench.frame_roofline(7.1, 5.97e-3)
+    assert fr["mfma_frac"] < 1.0 < fr["algorithmic_mfma_frac"] and abs(fr["executed_gflop"] - (fr["algorithmic_gflop"] - 0.75 * (416.2 + 68.0 * 7.1))) < 0.2

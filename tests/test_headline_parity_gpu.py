@@ -11,9 +11,14 @@ nearest clusters are equally far.  The tests therefore split the claim exactly t
   (a) embeddings: the HIP networks against the oracle's, on the stage-1 frames AND on the oracle's own crops  <= 1e-3
   (b) integer path: the ORACLE's embeddings (stage 1 and every crop) fed through the HIP clustering + ROI / match / paste
       kernels must reproduce the oracle's label maps bit-exactly — on every bench frame tested, no tolerance
-  (c) end to end (HIP embeddings -> HIP integer path) over all 1 024 frames of tests/golden/bench_oracle/: every pixel that
-      differs from the oracle's map must be a near-tie of the ORACLE's own run — nearest-seed margin (oracle/margins.py,
-      committed per frame in tests/golden/bench_margins/) at most TAU — and ZERO pixels may differ beyond it
+  (c) end to end (HIP embeddings -> HIP integer path) over all 1 024 frames of tests/golden/bench_oracle/ — round 5: the claim
+      rests on the EXACT leg.  For EVERY frame whose map differs from the fixture (~68 of 1 024) leg (b) runs automatically:
+      the oracle's stage-1 and crop embeddings through the HIP integer path must reproduce the oracle's maps with identical
+      ids.  Next to it, as the explanation of WHY a pixel moved: hard count bounds (worst frame <= 32 px, P99 <= 5), the margin
+      rule (nearest-seed margin of the oracle's own run, tests/golden/bench_margins/, at most TAU), and for pixels beyond TAU
+      a FROZEN perturbation protocol (oracle/margins.PERTURB_RUNS = 8 seeded runs of the oracle at 1x the measured embedding
+      error; the HIP networks are NOT an admissible witness; anything that needs more runs or a larger eps is reported as
+      `escalated`, bounded and never silently passed)
   (d) TAU is not a free parameter: the margin of a pixel between seeds a and b moves by at most |dx| + (|dz_a| + |dz_b|) / 2
       when its embedding moves by dx and the seeds by dz (L2 norms, unit vectors); (d) measures |dx| (HIP vs oracle
       embeddings) and |dz| (HIP vs oracle converged seeds, i.e. the embedding error through ten kappa = 20 iterations)
@@ -43,8 +48,13 @@ DECOMPOSED_FRAMES = int(os.environ.get("UOC_PARITY_FRAMES", "24"))     # frames 
 # permutation, 39 x 1, 12 x 2, 7 x 3, 3 x 4, 3 x 5 pixels, one frame 17 and one 24 pixels of 307 200 — and on those worst
 # frames the integer path is bit-exact given the oracle's embeddings, profiles/r03_parity_decomposed_outlier_frames.json)
 EMBED_EPS = 2.5e-6                     # per-component embedding error of the perturbed oracle runs: just below the measured HIP-vs-oracle maximum ((a): 2.5e-6 .. 2.8e-6; bar 1e-3)
-MAX_FLAGGED_FRAMES = 12                # frames (of 1 024) that may need the perturbation analysis (~30 s of oracle each); more = a regression
-E2E_MIN_EXACT_FRACTION = 0.90          # secondary alarm only: share of frames identical up to a permutation (measured 0.936)
+MAX_FLAGGED_FRAMES = 12                # frames (of 1 024) that may need the perturbation analysis (~60 s of oracle each); more = a regression
+MAX_ESCALATED_FRAMES = 2               # frames the frozen protocol (8 runs at 1x) does not cover and that needed more runs / 2x / 4x eps: reported, bounded (measured: see profiles/r05_parity_margins.json)
+E2E_MIN_EXACT_FRACTION = 0.90          # secondary alarm only: share of frames identical up to a permutation (measured 0.934)
+KERNEL_TAU = 1e-5                      # exact leg: a pixel may differ between the HIP and the oracle's integer path ON THE SAME EMBEDDINGS only if its margin in the oracle's own run is below the kernels' fp32 summation-order rounding (measured seed deviation dz_kernel 1e-7 .. 1.1e-6, profiles/r04_parity_tau.json; measured margins of such pixels: profiles/r05_parity_flagged_decomposed.json)
+MAX_KERNEL_ROUNDING_FRAMES = 8         # ... on at most this many of the ~68 mismatching frames (measured 3), one or two pixels each
+E2E_MAX_MISMATCHED_PIXELS = 32         # hard count bounds next to the margin rule: worst frame (measured 24) ...
+E2E_P99_MISMATCHED_PIXELS = 5          # ... and the 99th percentile over the frames (measured 4)
 
 
 def _fixture():
@@ -52,9 +62,9 @@ def _fixture():
     out = {}
     for path in sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "bench_oracle", "frames_*.npz"))):
         z = np.load(path)
-        first = int(z["first"])
-        for i in range(len(z["final"])):
-            out[first + i] = (z["stage1"][i], z["final"][i])
+        first, s1, fin = int(z["first"]), z["stage1"], z["final"]       # an NpzFile decompresses the whole array on every access
+        for i in range(len(fin)):
+            out[first + i] = (s1[i], fin[i])
     return out
 
 
@@ -84,6 +94,102 @@ def nets(device):
     return sd, net, net_crop
 
 
+def _memo(network):
+    """Caches a CPU network's output per input content (the perturbation runs of a frame reuse stage 1 and, while the stage-1
+    map is unchanged, the crops)."""
+    import hashlib
+    cache = {}
+
+    def net(image, label, depth):
+        key = (tuple(image.shape), hashlib.blake2b(image.numpy().tobytes(), digest_size=16).digest(),
+               hashlib.blake2b(depth.numpy().tobytes(), digest_size=16).digest())
+        if key not in cache:
+            if len(cache) > 6:
+                cache.clear()
+            cache[key] = network(image, label, depth)
+        return cache[key]
+    return net
+
+
+def _perturb_worker(args):
+    """One run of the frozen perturbation protocol in a worker process (the 8 runs of a frame are independent): the oracle's
+    base embeddings come from the parent through /dev/shm (stage 1; the crops as long as the perturbed stage-1 map leaves them
+    unchanged), anything else is recomputed with the oracle's network."""
+    g, index, eps, shm = args
+    torch.set_num_threads(8)
+    from oracle import margins as M
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    z = {k: torch.from_numpy(np.load(os.path.join(shm, k + ".npy"))) for k in ("f1", "rgb_c", "f2", "base")}
+    img, dep = _bench_frame(g)
+
+    def net(image, label, depth):
+        if image.shape == img.shape and torch.equal(image, img):
+            return z["f1"]
+        if image.shape == z["rgb_c"].shape and torch.equal(image, z["rgb_c"]):
+            return z["f2"]
+        return BO.segnet_forward(sd, image, depth)
+    return M.perturbation_run(img, dep, net, runner.frame_rng_seed(g), z["base"].numpy(), eps, index)
+
+
+def _decompose(g, fix, sd, net, net_crop, device, end_to_end=True, live_oracle_fallback=False):
+    """Legs (a) + (b) on bench frame g.  (b): the ORACLE's embeddings (stage 1, and its own crops rebuilt from its stage-1 map,
+    test_dataset.py:62-112) through the HIP clustering, depth filter, ROI table, crops' masks, match statistics and paste —
+    compared with the committed oracle maps id for id.  `live_oracle_fallback`: if the maps are not identical to the fixture
+    (made on another host), the oracle's own integer path runs HERE on the very same embeddings and the comparison is
+    repeated against that (which is what "given the oracle's embeddings" means to the last bit)."""
+    img, dep = _bench_frame(g)
+    want_out = torch.from_numpy(fix[g][0].astype(np.float32))[None]
+    want_final = fix[g][1]
+    f1 = BO.segnet_forward(sd, img, dep)
+    rgb_c, mask_c, rois, dep_c = GO.crop_rois(img, want_out.clone(), dep)
+    K = rgb_c.shape[0]
+    assert K >= 5, "the headline frames must exercise stage 2"
+    f2 = BO.segnet_forward(sd, rgb_c, dep_c)
+    # (a) HIP embeddings on the same inputs
+    e1 = net(img.to(device), None, dep.to(device)).cpu()
+    e2 = net_crop(rgb_c.to(device), None, dep_c.to(device)).cpu()
+    err1, err2 = float((e1 - f1).abs().max()), float((e2 - f2).abs().max())
+    # (b) the stubs ignore their inputs: stage 2 clusters the oracle's crop embeddings
+    stub1 = lambda image, label, depth: f1.to(device)
+    stub2 = lambda image, label, depth: f2.to(device)
+    np.random.seed(runner.frame_rng_seed(g))
+    got_out, got_ref = TD.test_sample(dict(image_color=img, depth=dep), stub1, stub2)
+    s1_same = bool(np.array_equal(got_out[0].numpy().astype(np.int64), want_out[0].numpy().astype(np.int64)))
+    fin_same = bool(got_ref is not None and np.array_equal(got_ref[0].numpy().astype(np.int64), want_final.astype(np.int64)))
+    row = {"frame": g, "rois": K, "embed_err_stage1": err1, "embed_err_crops": err2, "oracle_objects": int(want_final.max()),
+           "given_oracle_embeddings": {
+               "stage1_identical_ids": s1_same, "final_identical_ids": fin_same, "identical_to": "fixture" if s1_same and fin_same else None,
+               "stage1_exact_up_to_permutation": bool(O.labels_equal_up_to_permutation(got_out.numpy(), want_out.numpy())),
+               "final_exact_up_to_permutation": bool(got_ref is not None and O.labels_equal_up_to_permutation(got_ref[0].numpy(), want_final)),
+               "final_mismatched_pixels": _mismatch(got_ref[0].numpy(), want_final) if got_ref is not None else H * W}}
+    if live_oracle_fallback and not (s1_same and fin_same):
+        from oracle import margins as M
+        live_out, live_ref, info = M.test_sample_with_margins(img, dep, lambda *a: f1, lambda *a: f2,
+                                                              np.random.RandomState(runner.frame_rng_seed(g)))
+        l1 = bool(np.array_equal(got_out[0].numpy().astype(np.int64), live_out[0].numpy().astype(np.int64)))
+        lF = bool(got_ref is not None and live_ref is not None and
+                  np.array_equal(got_ref[0].numpy().astype(np.int64), live_ref[0].numpy().astype(np.int64)))
+        upd = dict(identical_to="the oracle's integer path on this host, same embeddings" if l1 and lF else None,
+                   live_stage1_identical_ids=l1, live_final_identical_ids=lF,
+                   live_oracle_vs_fixture_pixels=_mismatch(live_ref[0].numpy(), want_final) if live_ref is not None else None)
+        if not (l1 and lF) and got_ref is not None and live_ref is not None:
+            # the HIP kernels and torch's CPU mm sum the same products in different orders: the converged seeds differ by
+            # ~1e-7 .. 1e-6 (`dz_kernel` of test (d)), and a pixel whose margin in the oracle's OWN run is below that is decided by
+            # the last bit of either sum.  Report every such pixel with that margin; the caller bounds them (KERNEL_TAU).
+            px1 = M.label_changes(live_out[0].numpy(), got_out[0].numpy())
+            pxF = M.label_changes(live_ref[0].numpy(), got_ref[0].numpy())
+            upd["kernel_rounding_pixels"] = (
+                [{"map": "stage1", "y": int(p // W), "x": int(p % W), "margin": float(info["margin1"][p])} for p in px1.tolist()] +
+                [{"map": "final", "y": int(p // W), "x": int(p % W), "margin": float(info["marginF"].reshape(-1)[p])} for p in pxF.tolist()])
+        row["given_oracle_embeddings"].update(upd)
+    if end_to_end:
+        np.random.seed(runner.frame_rng_seed(g))
+        e2e_out, e2e_ref = TD.test_sample(dict(image_color=img, depth=dep), net, net_crop)
+        row["end_to_end_mismatched_pixels"] = _mismatch((e2e_ref if e2e_ref is not None else e2e_out)[0].numpy(), want_final)
+        row["end_to_end_objects"] = int((e2e_ref if e2e_ref is not None else e2e_out).max())
+    return row
+
+
 def test_embeddings_and_integer_path_separately(device, nets):
     """(a) + (b) on bench frames 0 .. DECOMPOSED_FRAMES-1."""
     sd, net, net_crop = nets
@@ -92,45 +198,14 @@ def test_embeddings_and_integer_path_separately(device, nets):
     if os.environ.get("UOC_PARITY_FRAME_LIST"):        # ad hoc: the decomposition on chosen frames, e.g. the histogram's outliers
         frames = [int(v) for v in os.environ["UOC_PARITY_FRAME_LIST"].split(",")]
     assert len(frames) >= min(DECOMPOSED_FRAMES, 8) or os.environ.get("UOC_PARITY_FRAME_LIST"), "tests/golden/bench_oracle/ is missing"
-    report, worst_embed = [], 0.0
-    for g in frames:
-        img, dep = _bench_frame(g)
-        want_out = torch.from_numpy(fix[g][0].astype(np.float32))[None]
-        want_final = fix[g][1]
-        # the oracle's embeddings: stage 1, and its own crops rebuilt from its stage-1 map (test_dataset.py:62-112)
-        f1 = BO.segnet_forward(sd, img, dep)
-        rgb_c, mask_c, rois, dep_c = GO.crop_rois(img, want_out.clone(), dep)
-        K = rgb_c.shape[0]
-        assert K >= 5, "the headline frames must exercise stage 2"
-        f2 = BO.segnet_forward(sd, rgb_c, dep_c)
-        # (a) HIP embeddings on the same inputs
-        e1 = net(img.to(device), None, dep.to(device)).cpu()
-        e2 = net_crop(rgb_c.to(device), None, dep_c.to(device)).cpu()
-        err1, err2 = float((e1 - f1).abs().max()), float((e2 - f2).abs().max())
-        worst_embed = max(worst_embed, err1, err2)
-        # (b) the oracle's embeddings through the HIP integer path (clustering, depth filter, ROI table, crops' masks,
-        # match statistics, paste).  The stubs ignore their inputs: stage 2 clusters the oracle's crop embeddings.
-        stub1 = lambda image, label, depth: f1.to(device)
-        stub2 = lambda image, label, depth: f2.to(device)
-        np.random.seed(runner.frame_rng_seed(g))
-        got_out, got_ref = TD.test_sample(dict(image_color=img, depth=dep), stub1, stub2)
-        s1_same = bool(np.array_equal(got_out[0].numpy().astype(np.int64), want_out[0].numpy().astype(np.int64)))
-        fin_same = bool(got_ref is not None and np.array_equal(got_ref[0].numpy().astype(np.int64), want_final.astype(np.int64)))
-        np.random.seed(runner.frame_rng_seed(g))
-        e2e_out, e2e_ref = TD.test_sample(dict(image_color=img, depth=dep), net, net_crop)
-        report.append({
-            "frame": g, "rois": K, "embed_err_stage1": err1, "embed_err_crops": err2,
-            "end_to_end_mismatched_pixels": _mismatch((e2e_ref if e2e_ref is not None else e2e_out)[0].numpy(), want_final),
-            "end_to_end_objects": int((e2e_ref if e2e_ref is not None else e2e_out).max()), "oracle_objects": int(want_final.max()),
-            "given_oracle_embeddings": {
-                "stage1_identical_ids": s1_same, "final_identical_ids": fin_same,
-                "stage1_exact_up_to_permutation": bool(O.labels_equal_up_to_permutation(got_out.numpy(), want_out.numpy())),
-                "final_exact_up_to_permutation": bool(got_ref is not None and O.labels_equal_up_to_permutation(got_ref[0].numpy(), want_final)),
-                "final_mismatched_pixels": _mismatch(got_ref[0].numpy(), want_final) if got_ref is not None else H * W}})
+    report = [_decompose(g, fix, sd, net, net_crop, device, live_oracle_fallback=bool(os.environ.get("UOC_PARITY_FRAME_LIST"))) for g in frames]
+    worst_embed = max(max(r["embed_err_stage1"], r["embed_err_crops"]) for r in report)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     summary = {"frames": len(frames), "embed_max_err": worst_embed,
                "exact_given_oracle_embeddings": all(r["given_oracle_embeddings"]["final_exact_up_to_permutation"] and
                                                     r["given_oracle_embeddings"]["stage1_exact_up_to_permutation"] for r in report),
+               "identical_ids_given_oracle_embeddings": all(r["given_oracle_embeddings"]["final_identical_ids"] and
+                                                            r["given_oracle_embeddings"]["stage1_identical_ids"] for r in report),
                "per_frame": report}
     json.dump(summary, open(os.path.join(ROOT, "gpurun_out", "parity_decomposed.json"), "w"), indent=1)
     print(json.dumps({k: v for k, v in summary.items() if k != "per_frame"}))
@@ -166,12 +241,20 @@ def _frame_pair(g):
 
 
 def test_end_to_end_margin_bounded(device, nets):
-    """(c) north_star's "integer labels bit-exact up to label permutation" in the only form fp32 allows, on every frame
-    of BASELINE configs[4] (1 024 by default): HIP embeddings -> HIP integer path through the frame-parallel runner in
-    the launch shape bench.py times, against the oracle's final maps — and EVERY pixel that differs must be one whose
-    decision the reference's own arithmetic does not resolve: its nearest-seed margin in the oracle's run (oracle's
-    embeddings, oracle's converged seeds, mean_shift.py:211-214 through the paste of test_dataset.py:172-177) is at most
-    TAU.  Zero pixels may differ with a margin above TAU."""
+    """(c) north_star's "integer labels bit-exact up to label permutation" on every frame of BASELINE configs[4] (1 024 by
+    default): HIP embeddings -> HIP integer path through the frame-parallel runner in the launch shape bench.py times,
+    against the oracle's final maps.  The claim, in the order of its strength:
+      1. EXACT: for every frame whose map differs from the oracle's, the oracle's embeddings through the HIP integer path
+         reproduce the oracle's maps id for id (leg (b), `_decompose`; compared with the committed fixture, and — only if the
+         fixture's host rounded an embedding differently — with the oracle's integer path run here on the same embeddings).
+         Measured: 65 of 68 frames; on the other 3 ONE pixel differs whose margin in the oracle's own run is below the
+         fp32 summation-order rounding of the kernels (KERNEL_TAU = 1e-5, 50x below TAU; the HIP kernels and torch's CPU mm
+         add the same products in different orders) — listed with their margins, at most MAX_KERNEL_ROUNDING_FRAMES frames;
+      2. BOUNDED: worst frame <= 32 mismatching pixels, 99th percentile <= 5;
+      3. EXPLAINED: every mismatching pixel is a near-tie of the oracle's own run (margin <= TAU) or, beyond TAU, a pixel the
+         oracle itself flips under the FROZEN perturbation protocol (8 seeded runs at 1x the measured embedding error).
+         Pixels that need more are `escalated`: reported, at most MAX_ESCALATED_FRAMES frames; unexplained pixels fail."""
+    import time
     from concurrent.futures import ProcessPoolExecutor
     import multiprocessing as mp
     from oracle import margins as M
@@ -183,8 +266,9 @@ def test_end_to_end_margin_bounded(device, nets):
     n = min(n, int(os.environ.get("UOC_PARITY_E2E_FRAMES", "1024")))
     assert n >= 8, "tests/golden/bench_oracle/ or bench_margins/ is missing"
     CH = 64                                   # frames resident at a time (7.4 MB each)
-    hist, per_frame, pixels, beyond, worst_margin, flagged, bifurcated = {}, [], [], [], 0.0, [], []
+    hist, per_frame, pixels, beyond, worst_margin, flagged, bifurcated, mismatching = {}, [], [], [], 0.0, [], [], []
     workers = max(1, min(32, len(os.sched_getaffinity(0)) - 2))
+    t_start = time.time()
     with ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as pool:     # spawn: this process holds a HIP context
         chunks = [(lo, min(n, lo + CH)) for lo in range(0, n, CH)]
         pending = pool.map(_frame_pair, range(0, n), chunksize=4)       # host-side synthesis runs ahead of the GPU
@@ -202,6 +286,7 @@ def test_end_to_end_margin_bounded(device, nets):
                 hist[len(bad)] = hist.get(len(bad), 0) + 1
                 if len(bad) == 0:
                     continue
+                mismatching.append(g)
                 m = _lookup(mar[g]["idxF"], mar[g]["valF"], bad)
                 over = m > M.TAU
                 if over.any():
@@ -210,42 +295,101 @@ def test_end_to_end_margin_bounded(device, nets):
                 worst_margin = max(worst_margin, float(m.max()))
                 for p, v in zip(bad.tolist(), m.tolist()):
                     pixels.append({"frame": g, "y": p // W, "x": p % W, "margin": round(v, 9), "class": "near_tie"})
-    # Frames with a pixel beyond the margin: either a regression, or a seed between two modes (oracle/margins.py: the
-    # margin bounds the assignment GIVEN the seeds; at such a seed the oracle's own result flips with the last bit of a
-    # sum — bench frame 246: 1 vs 4 torch threads).  Ask the oracle: its whole path again with the embeddings perturbed by
-    # the measured embedding error (seeded sign patterns; at least 3 runs, up to 24, the late ones at 2x / 4x) and once on the HIP networks' embeddings; every mismatching pixel must
-    # be one whose label changes in at least one of those runs, or a near-tie of this host's oracle run, or a pixel on
-    # which this host's oracle run itself differs from the committed one.
+    t_e2e = time.time() - t_start
+    # ---- 1. the exact leg on EVERY mismatching frame ----
+    t_start = time.time()
+    decomposed = [_decompose(g, fix, sd, net, net_crop, device, end_to_end=False, live_oracle_fallback=True) for g in mismatching]
+    t_dec = time.time() - t_start
+    def _rounding_only(r):
+        px = r["given_oracle_embeddings"].get("kernel_rounding_pixels")
+        return bool(px) and len(px) <= 2 and all(p["margin"] <= KERNEL_TAU for p in px)
+    rounding = [r["frame"] for r in decomposed if r["given_oracle_embeddings"]["identical_to"] is None and _rounding_only(r)]
+    not_exact = [r["frame"] for r in decomposed if r["given_oracle_embeddings"]["identical_to"] is None and not _rounding_only(r)]
+    dec = {"frames": [r["frame"] for r in decomposed], "count": len(decomposed),
+           "kernel_tau": KERNEL_TAU, "differ_by_a_pixel_below_the_kernels_rounding": rounding,
+           "largest_margin_of_such_a_pixel": max([p["margin"] for r in decomposed for p in r["given_oracle_embeddings"].get("kernel_rounding_pixels", [])] or [0.0]),
+           "identical_ids_to_the_fixture": sum(r["given_oracle_embeddings"]["identical_to"] == "fixture" for r in decomposed),
+           "identical_ids_to_the_oracle_on_this_host_only": sum((r["given_oracle_embeddings"]["identical_to"] or "").startswith("the oracle") for r in decomposed),
+           "not_identical": not_exact, "embed_max_err": max([max(r["embed_err_stage1"], r["embed_err_crops"]) for r in decomposed] or [0.0]),
+           "seconds": round(t_dec, 1), "per_frame": decomposed}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(dec, open(os.path.join(ROOT, "gpurun_out", "parity_flagged_decomposed.json"), "w"), indent=1)
+    print(json.dumps({k: v for k, v in dec.items() if k != "per_frame"}))
+    # ---- 3. frames with a pixel beyond the margin: either a regression, or a seed between two modes (oracle/margins.py: the
+    # margin bounds the assignment GIVEN the seeds; at such a seed the oracle's own result flips with the last bit of a sum —
+    # bench frame 246: 1 vs 4 torch threads).  Ask the ORACLE, by the frozen protocol: its whole path again with its own
+    # embeddings perturbed by the measured embedding error, M.PERTURB_RUNS seeded sign patterns at 1x.  A mismatching pixel is
+    # explained if its label changes in one of those runs, or it is a near-tie of this host's oracle run, or this host's oracle
+    # run itself differs from the committed one there.  What is left goes to the escalation (more runs, 2x / 4x eps) and is
+    # REPORTED as escalated; what even that does not cover fails the test.
     assert len(flagged) <= MAX_FLAGGED_FRAMES, [f[0] for f in flagged]
-    cpu_net = lambda image, label, depth: BO.segnet_forward(sd, image, depth)
-    hip1 = lambda image, label, depth: net(image.to(device), None, depth.to(device)).cpu()
-    hip2 = lambda image, label, depth: net_crop(image.to(device), None, depth.to(device)).cpu()
+    import shutil
+    import tempfile
+    cpu_net = _memo(lambda image, label, depth: BO.segnet_forward(sd, image, depth))
+    t_start = time.time()
+    escalated_frames = []
+    shm = tempfile.mkdtemp(prefix="uoc_parity_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    pert_pool = ProcessPoolExecutor(min(M.PERTURB_RUNS, max(1, len(os.sched_getaffinity(0)) // 8)), mp_context=mp.get_context("spawn"))
     for g, bad, m in flagged:
         img, dep = _bench_frame(g)
-        # pixels the committed near-tie set does not explain: the perturbation runs continue (up to 24) until they do
-        changed, base, info, used = M.unresolved_pixels(img, dep, cpu_net, runner.frame_rng_seed(g), EMBED_EPS, runs=3,
-                                                        extra_networks=[(hip1, hip2)], need=bad[m > M.TAU])
+        seen = []
+        rec_net = lambda image, label, depth: (seen.append((image, cpu_net(image, label, depth))) or seen[-1][1])
+
+        def run_many(base, indices, g=g):        # the protocol's runs, side by side in worker processes
+            np.save(os.path.join(shm, "f1.npy"), seen[0][1].numpy())
+            np.save(os.path.join(shm, "rgb_c.npy"), seen[-1][0].numpy())
+            np.save(os.path.join(shm, "f2.npy"), seen[-1][1].numpy())
+            np.save(os.path.join(shm, "base.npy"), np.asarray(base))
+            return list(pert_pool.map(_perturb_worker, [(g, i, EMBED_EPS, shm) for i in indices]))
+        changed, base, info, per_run = M.unresolved_pixels(img, dep, rec_net, runner.frame_rng_seed(g), EMBED_EPS, run_many=run_many)
         here_vs_there = M.label_changes(fix[g][1], base)
-        ok = np.isin(bad, changed) | np.isin(bad, here_vs_there) | (m <= M.TAU) | (info["marginF"].reshape(-1)[bad] <= M.TAU)
-        for p, v, good in zip(bad.tolist(), m.tolist(), ok.tolist()):
-            pixels.append({"frame": g, "y": p // W, "x": p % W, "margin": (round(v, 9) if np.isfinite(v) else None),
-                           "class": "unresolved_by_the_oracle" if good else "BEYOND_MARGIN"})
-        bifurcated.append({"frame": g, "mismatching_pixels": int(len(bad)), "beyond_tau": int((m > M.TAU).sum()),
-                           "pixels_the_oracle_flips_under_perturbation": int(len(changed)), "perturbed_oracle_runs": used + 1,
-                           "oracle_here_vs_fixture_pixels": int(len(here_vs_there)), "unexplained": int((~ok).sum())})
+        near = (m <= M.TAU) | (info["marginF"].reshape(-1)[bad] <= M.TAU)
+        ok = np.isin(bad, changed) | np.isin(bad, here_vs_there) | near
+        esc_ok, esc_used, esc_factor = np.zeros(len(bad), bool), 0, 1
         if not ok.all():
+            extra, esc_used, esc_factor = M.escalated_pixels(img, dep, cpu_net, runner.frame_rng_seed(g), base, EMBED_EPS, bad[~ok])
+            esc_ok = ~ok & np.isin(bad, extra)
+            escalated_frames.append(g)
+        for p, v, good, nr, esc in zip(bad.tolist(), m.tolist(), ok.tolist(), near.tolist(), esc_ok.tolist()):
+            pixels.append({"frame": g, "y": p // W, "x": p % W, "margin": (round(v, 9) if np.isfinite(v) else None),
+                           "class": "near_tie" if nr else "unresolved_by_the_oracle" if good else "escalated" if esc else "BEYOND_MARGIN"})
+        need, acc, first_cover = bad[m > M.TAU], np.zeros(0, np.int64), None
+        for i, c in enumerate(per_run):
+            acc = np.union1d(acc, c)
+            if np.isin(need, acc).all():
+                first_cover = i + 1
+                break
+        bifurcated.append({"frame": g, "mismatching_pixels": int(len(bad)), "beyond_tau": int((m > M.TAU).sum()),
+                           "pixels_the_oracle_flips_under_perturbation": int(len(changed)), "protocol_runs": len(per_run),
+                           "runs_until_covered": first_cover, "escalation_runs": esc_used, "escalation_eps_factor": esc_factor,
+                           "escalated_pixels": int(esc_ok.sum()),
+                           "oracle_here_vs_fixture_pixels": int(len(here_vs_there)), "unexplained": int((~ok & ~esc_ok).sum())})
+        if not (ok | esc_ok).all():
             beyond.append(bifurcated[-1])
+    pert_pool.shutdown()
+    shutil.rmtree(shm, ignore_errors=True)
+    t_pert = time.time() - t_start
     exact = hist.get(0, 0) / n
-    out = {"frames": n, "tau": M.TAU, "mismatching_pixels": len(pixels), "pixels_total": n * H * W,
+    srt = sorted(per_frame)
+    p99 = srt[min(len(srt) - 1, int(np.ceil(0.99 * len(srt))) - 1)]
+    out = {"frames": n, "tau": M.TAU, "mismatching_frames": len(mismatching), "mismatching_pixels": len(pixels), "pixels_total": n * H * W,
+           "worst_frame_pixels": max(per_frame), "p99_frame_pixels": p99,
+           "exact_leg_on_every_mismatching_frame": {k: v for k, v in dec.items() if k not in ("per_frame", "frames")},
            "mismatches_unexplained": int(sum(b["unexplained"] for b in beyond)), "largest_margin_of_a_near_tie_mismatch": worst_margin,
-           "embedding_perturbation": EMBED_EPS, "frames_with_an_unresolved_seed": bifurcated,
+           "embedding_perturbation": EMBED_EPS, "perturbation_protocol": f"{M.PERTURB_RUNS} seeded runs of the oracle at 1x eps, oracle embeddings only",
+           "escalated_frames": escalated_frames, "frames_with_an_unresolved_seed": bifurcated,
            "exact_fraction": exact, "histogram_mismatched_pixels": {str(k): hist[k] for k in sorted(hist)},
+           "seconds": {"end_to_end": round(t_e2e, 1), "exact_leg": round(t_dec, 1), "perturbation": round(t_pert, 1)},
            "beyond": beyond, "pixels": pixels, "per_frame": per_frame}
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "parity_margins.json"), "w"))
     print(json.dumps({k: v for k, v in out.items() if k not in ("per_frame", "pixels")}))
-    assert not beyond, beyond                                   # the claim: nothing differs beyond the margin
+    assert not not_exact, f"integer path not identical given the oracle's embeddings on frames {not_exact}"      # 1. the exact leg
+    assert len(rounding) <= MAX_KERNEL_ROUNDING_FRAMES, rounding
+    assert dec["embed_max_err"] <= 1e-3
+    assert max(per_frame) <= E2E_MAX_MISMATCHED_PIXELS and p99 <= E2E_P99_MISMATCHED_PIXELS, (max(per_frame), p99)   # 2. counts
+    assert not beyond, beyond                                   # 3. nothing differs beyond the margin unexplained
     assert worst_margin <= M.TAU
+    assert len(escalated_frames) <= MAX_ESCALATED_FRAMES, escalated_frames
     # secondary (a coarse regression alarm, not the claim): most frames are identical outright
     assert exact >= E2E_MIN_EXACT_FRACTION, out["histogram_mismatched_pixels"]
 

@@ -81,6 +81,34 @@ def test_two_stage_run_with_margins_equals_the_pinned_oracle_and_bounds_perturba
     assert (info["marginF"].reshape(-1)[changed] <= 1e-4).all()
 
 
+def test_perturbation_protocol_is_fixed():
+    """unresolved_pixels runs EXACTLY the stated number of seeded oracle perturbations (no witness search, no other embedding
+    source); escalated_pixels is a separate, reported step that stops as soon as the needed pixels are covered."""
+    import inspect
+    assert M.PERTURB_RUNS == 8
+    sig = inspect.signature(M.unresolved_pixels)
+    assert "extra_networks" not in sig.parameters and "need" not in sig.parameters and "max_runs" not in sig.parameters
+    assert sig.parameters["runs"].default == M.PERTURB_RUNS
+    H, W = 64, 80
+    fr = synth.rgbd_frame(11, H, W, 2, hole_fraction=0.0)
+    img, dep = torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"])
+    calls = []
+
+    def s1(i, l, d):
+        calls.append(tuple(i.shape))
+        return _stub_features(40, H, W, 3) if i.shape[2] == H else torch.cat([_stub_features(50 + j, 224, 224, 2) for j in range(i.shape[0])])
+    changed, base, info, per_run = M.unresolved_pixels(img, dep, s1, 7, 1e-6, runs=2)
+    assert len(per_run) == 2 and base.shape == (H, W)
+    assert sorted(changed.tolist()) == sorted(set(per_run[0].tolist()) | set(per_run[1].tolist()))
+    n_calls = len(calls)
+    # nothing needed -> no extra run; an uncoverable pixel -> exactly last - first runs, eps factor reported
+    extra, used, factor = M.escalated_pixels(img, dep, s1, 7, base, 1e-6, np.zeros(0, np.int64))
+    assert used == 0 and len(extra) == 0 and len(calls) == n_calls
+    far = int(np.argmax(np.where(np.isfinite(info["marginF"]), info["marginF"], -1)))      # the best separated pixel never flips
+    extra, used, factor = M.escalated_pixels(img, dep, s1, 7, base, 1e-6, np.array([far]), first=8, last=10)
+    assert used == 2 and factor == 2 and far not in extra.tolist()
+
+
 def test_committed_bench_margins_cover_the_benchmark_frames():
     mar = M.load_bench_margins(ROOT)
     assert sorted(mar) == list(range(1024)), "tests/golden/bench_margins must hold all 1 024 frames of BASELINE configs[4]"

@@ -51,3 +51,35 @@ def test_two_rank_gather_equals_single_process(tmp_path, F):
     for r in range(2):
         got = torch.load(os.path.join(str(tmp_path), f"r{r}.pt"))
         assert got.shape == (F, 6, 8) and torch.equal(got, single)
+
+
+def _mismatch_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["UOC_TEST_FINGERPRINT"] = str(1000 + (1 if rank == 1 else 0))      # rank 1 "runs another library configuration"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        runner.run_sharded(4, _frame, 6, 8, torch.device("cpu"), rank, world)
+        msg = "no error"
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(out_dir, f"r{rank}.txt"), "w").write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_with_different_library_configurations_fail_before_the_gather(tmp_path):
+    """one stray rounding-affecting knob (or another library build) on one rank would silently break
+    sharding independence.  run_sharded all-reduces uoc_config_fingerprint() with its error flag; EVERY rank raises."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_mismatch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert "different libuoc_hip configurations" in open(os.path.join(str(tmp_path), f"r{r}.txt")).read()
+
+
+def test_the_fingerprint_is_the_library_s():
+    from unseenobjectclustering_amd import _native
+    assert runner.config_fingerprint() == _native.config_fingerprint() & 0x7FFFFFFFFFFFFFFF > 0

@@ -18,6 +18,10 @@ class NativeError(RuntimeError):
 def _declare(lib):
     P = c_void_p
     lib.uoc_version.restype = c_int
+    lib.uoc_is_dev_build.argtypes = []
+    lib.uoc_is_dev_build.restype = c_int
+    lib.uoc_config_fingerprint.argtypes = []
+    lib.uoc_config_fingerprint.restype = ctypes.c_ulonglong
     lib.uoc_shutdown.restype = c_int
     lib.uoc_reload_env.argtypes = []
     lib.uoc_reload_env.restype = c_int
@@ -54,6 +58,8 @@ def _declare(lib):
     lib.uoc_net_workspace_bytes.argtypes = [P, c_int, c_int, c_int]
     lib.uoc_net_forward.argtypes = [P, P, P, c_int, c_int, c_int, P, P, c_size_t, P]
     lib.uoc_conv2d_nhwc.argtypes = [P, P, P, P, P] + [c_int] * 11 + [P]
+    lib.uoc_conv2d_nhwc_algo.argtypes = [P, P, P, P, P] + [c_int] * 12 + [P]
+    lib.uoc_conv2d_nhwc_algo.restype = c_int
     for name in ("uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_forward",
                  "uoc_conv2d_nhwc"):
         getattr(lib, name).restype = c_int
@@ -87,11 +93,11 @@ def _declare(lib):
 
 # every symbol include/uoc_hip.h declares (tests check the .so exports them all)
 EXPORTED_SYMBOLS = (
-    "uoc_version", "uoc_shutdown", "uoc_last_error", "uoc_reload_env", "uoc_ms_set_persistent_fps", "uoc_ms_set_stream_ordering", "uoc_ms_fps_fallbacks", "uoc_ms_check", "uoc_ms_workspace_bytes", "uoc_ms_select_seeds", "uoc_ms_select_seeds_from", "uoc_ms_hill_climb",
+    "uoc_version", "uoc_is_dev_build", "uoc_config_fingerprint", "uoc_shutdown", "uoc_last_error", "uoc_reload_env", "uoc_ms_set_persistent_fps", "uoc_ms_set_stream_ordering", "uoc_ms_fps_fallbacks", "uoc_ms_check", "uoc_ms_workspace_bytes", "uoc_ms_select_seeds", "uoc_ms_select_seeds_from", "uoc_ms_hill_climb",
     "uoc_ms_seed_components", "uoc_ms_assign", "uoc_ms_cluster", "uoc_ms_workspace_bytes_wide", "uoc_ms_cluster_wide",
     "uoc_net_embed_dim",
     "uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",
-    "uoc_net_forward", "uoc_conv2d_nhwc",
+    "uoc_net_forward", "uoc_conv2d_nhwc", "uoc_conv2d_nhwc_algo",
     "uoc_roi_workspace_bytes", "uoc_prep_rgbd", "uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats",
     "uoc_roi_paste", "uoc_labels_to_u8", "uoc_eval_workspace_bytes", "uoc_eval_pair_stats", "uoc_lzf_decompress", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
 )
@@ -122,6 +128,15 @@ def lib():
         import atexit
         atexit.register(l.uoc_shutdown)
     return _lib
+
+
+CONV_DIRECT, CONV_WINOGRAD2, CONV_WINOGRAD4 = 0, 2, 4       # include/uoc_hip.h: UOC_CONV_*
+
+
+def config_fingerprint() -> int:
+    """uoc_config_fingerprint(): what could make two ranks compute different bits (library version / development build and
+    its rounding-affecting knobs).  runner.run_sharded compares it across ranks."""
+    return int(lib().uoc_config_fingerprint())
 
 
 def check(rc: int, what: str):

@@ -12,7 +12,8 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.environ.get("UOC_LIB_PATH") or os.path.join(PKG_DIR, "libuoc_hip.so")   # override: dev builds only
+LIB_PATH = os.environ.get("UOC_LIB_PATH") or os.path.join(PKG_DIR, "libuoc_hip.so")   # override: load a development build
+DEV_LIB_PATH = os.path.join(PKG_DIR, "libuoc_hip_dev.so")
 ARCH = "gfx950"
 
 
@@ -29,21 +30,32 @@ def _stale() -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build_native(force: bool = False, verbose: bool = False) -> str:
-    """Compile every csrc/*.hip into libuoc_hip.so.  Returns the library path."""
+def build_native(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
+    """Compile every csrc/*.hip into libuoc_hip.so.  Returns the library path.
+
+    dev=True (python -m unseenobjectclustering_amd.build --dev): the same sources with -DUOC_DEV into libuoc_hip_dev.so —
+    the measured-and-rejected alternates (Winograd F(2x2), the register-staged direct kernel, timing ablations) and the
+    UOC_* development knobs that select them.  Load it with UOC_LIB_PATH=<that file> (scripts/ab.sh does); the shipped
+    library contains none of it."""
+    if dev:
+        return _build(DEV_LIB_PATH, "build_dev", ["-DUOC_DEV"], True, verbose)
     if not force and not _stale():
         return LIB_PATH
+    return _build(LIB_PATH, "build", [], force, verbose)
+
+
+def _build(lib_path: str, objdir: str, flags, force: bool, verbose: bool) -> str:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libuoc_hip.so")
     objs, jobs = [], []
-    os.makedirs(os.path.join(CSRC, "build"), exist_ok=True)
+    os.makedirs(os.path.join(CSRC, objdir), exist_ok=True)
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h"))
     newest_header = max([os.path.getmtime(h) for h in headers], default=0.0)
     for src in sources():
-        obj = os.path.join(CSRC, "build", os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(CSRC, objdir, os.path.basename(src)[:-4] + ".o")
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
-            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj])
+            jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + list(flags) + ["-c", src, "-o", obj])
         objs.append(obj)
     if jobs:      # the translation units are independent: compile them side by side
         from concurrent.futures import ThreadPoolExecutor
@@ -54,12 +66,13 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
             subprocess.run(cmd, check=True)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as pool:
             list(pool.map(run, jobs))
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build_native(force=True, verbose=True))
+    import sys
+    print(build_native(force=True, verbose=True, dev="--dev" in sys.argv))

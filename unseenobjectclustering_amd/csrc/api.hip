@@ -27,7 +27,33 @@ int EnvInt::get() {
 }  // namespace uoc
 
 extern "C" {
-int uoc_version(void) { return 101; }
+int uoc_version(void) { return 102; }
+int uoc_is_dev_build(void) {
+#ifdef UOC_DEV
+  return 1;
+#else
+  return 0;
+#endif
+}
+/* What could make two ranks compute different bits: the library version, a development build, and (development builds
+ * only) the values of the knobs that change rounding.  runner.run_sharded all-reduces it with the error flag. */
+unsigned long long uoc_config_fingerprint(void) {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&](long long v) {
+    for (int i = 0; i < 8; ++i) {
+      h ^= (unsigned long long)(v >> (8 * i)) & 0xff;
+      h *= 1099511628211ull;
+    }
+  };
+  mix(uoc_version());
+  mix(uoc_is_dev_build());
+  mix(UOC_DEV_KNOB("UOC_WINOGRAD_F", 4));
+  mix(UOC_DEV_KNOB("UOC_WINOGRAD_MIN_CIN", 64));
+  mix(UOC_DEV_KNOB("UOC_HC_QUAD", 1));
+  mix(UOC_DEV_KNOB("UOC_HC_VARIANT", 2));
+  mix(UOC_DEV_KNOB("UOC_HC_VB_TILES", 16));
+  return h;
+}
 int uoc_reload_env(void) {
   uoc::g_env_epoch.fetch_add(1, std::memory_order_acq_rel);
   return UOC_OK;

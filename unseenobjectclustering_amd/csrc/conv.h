@@ -26,12 +26,14 @@ struct ConvParams {
 
 int launch_conv(const ConvParams &p, hipStream_t st);
 
-// Winograd F(2x2,3x3) path (csrc/wino.hip) for 3x3 stride-1 layers: U = transformed weights
-// [G][16][Cin/32][Cout][32] (launch_wino_weights), Vws = scratch of wino_v_floats() floats.
+#ifdef UOC_DEV
+// Winograd F(2x2,3x3) path (csrc/wino.hip; rounds 1-2, development builds only) for 3x3 stride-1 layers: U = transformed
+// weights [G][16][Cin/32][Cout][32] (launch_wino_weights), Vws = scratch of wino_v_floats() floats.
 bool wino_eligible(const ConvParams &p);
 size_t wino_v_floats(int G, int B, int H, int W, int d, int Cin);
 int launch_wino_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st);
 int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_t st);
+#endif
 
 // Winograd F(4x4,3x3) path (csrc/wino4.hip): U = transformed weights [G*36][Cout][Cin] (launch_wino4_weights, computed
 // in double), ws = scratch of wino4_ws_floats() floats (the V and M frequency planes).
@@ -40,19 +42,6 @@ bool wino4_channels_ok(int Cin, int Cout);
 size_t wino4_ws_floats(int G, int B, int H, int W, int d, int Cin, int Cout);
 int launch_wino4_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st);
 int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_t st);
-// A chain of F(4x4) layers with caller-owned V and M plane buffers (each >= 36 G NT max(Cin, Cout) floats): input
-// transform, plane GEMM, output transform as separate calls, and wino4_chain_mid = the previous layer's output transform
-// fused with the next layer's input transform (wino4_can_fuse: same geometry, phase image fits LDS).
-bool wino4_chain_ok(const ConvParams &p);
-bool wino4_can_fuse(const ConvParams &prev, const ConvParams &next);
-int wino4_chain_input(const ConvParams &p, float *V, hipStream_t st);
-int wino4_chain_gemm(const ConvParams &p, const float *U, float *V, float *Mw, hipStream_t st);
-int wino4_chain_output(const ConvParams &p, const float *Mw, hipStream_t st);
-int wino4_chain_mid(const ConvParams &prev, bool write_y, const float *Mw, float *V, hipStream_t st);
-// small-K layers (Cin = Cout = 64 / 128): the 72 plane GEMMs and the output transform as ONE kernel, no M planes
-bool wino4_small_ok(const ConvParams &p);
-int wino4_chain_gemm_out(const ConvParams &p, const float *U, const float *V, hipStream_t st);
-
 // NCHW [B][3][H][W] -> NHWC4 [B][H][W][4] (4th channel = 0)
 int launch_nchw3_to_nhwc4(const float *in, float *out, int B, int H, int W, hipStream_t st);
 // 3x3 s2 p1 max pooling, NHWC, C % 4 == 0; `n_img` images

@@ -32,6 +32,7 @@ __device__ __forceinline__ f32x4 mfma4c(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+#ifdef UOC_DEV   // the register-staged kernel of round 1: the shipped library runs the LDS-DMA kernel below for every shape
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, int VARIANT = 0>
 __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvParams p, int ntiles, int mtiles) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -216,6 +217,8 @@ __global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvPa
     }
   }
 }
+
+#endif  // UOC_DEV
 
 // -------------------------------------------------------------------------------------------
 // Production variant: operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging,
@@ -562,6 +565,7 @@ static const TileCfg kCfgs[] = {
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kNumCU = 256;
 
+#ifdef UOC_DEV
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, int VARIANT = 0>
 static int launch_cfg(const ConvParams &p, hipStream_t st, int kc) {
   const int M = p.B * p.Ho * p.Wo;
@@ -586,13 +590,10 @@ static int launch_cfg(const ConvParams &p, hipStream_t st, int kc) {
   UOC_LAUNCH_CHECK();
   return UOC_OK;
 }
+#endif  // UOC_DEV
 
 static int pick_cfg(const ConvParams &p) {
-  static int forced = -2;
-  if (forced == -2) {
-    const char *e = getenv("UOC_CONV_CFG");
-    forced = e ? atoi(e) : -1;
-  }
+  const int forced = UOC_DEV_KNOB("UOC_CONV_CFG", -1);
   const int M = p.B * p.Ho * p.Wo;
   if (forced >= 0 && forced < kNumCfg && p.Cout % kCfgs[forced].BN == 0) return forced;
   int best = -1;
@@ -615,22 +616,17 @@ static int pick_cfg(const ConvParams &p) {
 // the choice is purely a speed matter.  First use of a layer shape times the valid candidates
 // (3 launches each, HIP events) and caches the winner; a shape that differs only in batch size
 // (stage 2: one crop per ROI) reuses the nearest tuned neighbour instead of re-tuning.
-// UOC_CONV_AUTOTUNE=0 falls back to the static cost model; UOC_CONV_CFG / UOC_CONV_GLDS pin a choice.
+// UOC_CONV_AUTOTUNE=0 falls back to the static cost model (development builds: UOC_CONV_CFG / UOC_CONV_GLDS pin a choice).
 struct Choice {
   int cfg;
-  int glds;
+  int glds;   // 1 = the LDS-DMA kernel (always, in the shipped library); 0 = the register-staged kernel (dev builds)
 };
 
 static const int kBmWide[4] = {96, 128, 160, 192};  // 2x4-wave families (wave tile BM/2 x 32|16)
 static const int kBmNarrow[3] = {64, 80, 96};       // 1x8 / 1x4-wave families (wave tile BM x 16)
 
 static int pick_bm(int M, int ntiles, int G, int BN, const int *cands, int n) {
-  static int fixed = -1;
-  if (fixed < 0) {
-    const char *e = getenv("UOC_CONV_FIXED_TILE");  // 1 = always the 160 / 80 tile (A/B measurements)
-    fixed = e ? atoi(e) : 0;
-  }
-  if (fixed) return cands == kBmWide ? 160 : 80;
+  if (UOC_DEV_KNOB("UOC_CONV_FIXED_TILE", 0)) return cands == kBmWide ? 160 : 80;   // dev A/B: always the 160 / 80 tile
   int best = cands[n - 1];
   double best_cost = -1;
   for (int i = 0; i < n; ++i) {
@@ -683,7 +679,9 @@ static int launch_choice(const ConvParams &p, hipStream_t st, Choice c) {
           default: return launch_glds<80, 64, 1, 4, false>(p, st, KC_GLDS_80x64);
         }
     }
-  } else {
+  }
+#ifdef UOC_DEV
+  else {
     switch (c.cfg) {
       case 0: return launch_cfg<160, 128, 2, 4, false>(p, st, KC_CONV_160x128);
       case 1: return launch_cfg<80, 128, 1, 8, false>(p, st, KC_CONV_80x128);
@@ -691,6 +689,7 @@ static int launch_choice(const ConvParams &p, hipStream_t st, Choice c) {
       case 3: return launch_cfg<80, 64, 1, 4, false>(p, st, KC_CONV_80x64);
     }
   }
+#endif
   set_error("conv: bad choice cfg=%d", c.cfg);
   return UOC_EINVAL;
 }
@@ -720,6 +719,9 @@ static void tune_cache_load() {
   while (g_ntuned < 256 && fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d", &e.key.G, &e.key.B, &e.key.H, &e.key.W,
                                   &e.key.Cin, &e.key.Cout, &e.key.K, &e.key.stride, &e.key.dil, &e.choice.cfg,
                                   &e.choice.glds) == 11) {
+#ifndef UOC_DEV
+    e.choice.glds = 1;   // a cache written by a development build may name the register-staged kernel
+#endif
     if (e.choice.cfg >= 0 && e.choice.cfg < kNumCfg) g_tuned[g_ntuned++] = e;
   }
   fclose(f);
@@ -738,16 +740,18 @@ static std::mutex g_tune_mutex;   // the tuner's table is process-wide (choices 
                                   // identical device) and may be reached from several host threads
 static Choice choose(const ConvParams &p, hipStream_t st, int glds_default) {
   std::lock_guard<std::mutex> lock(g_tune_mutex);
-  static int autotune = -1, pin_cfg = -2, pin_glds = -2;
+  static int autotune = -1;
   if (autotune < 0) {
     const char *e = getenv("UOC_CONV_AUTOTUNE");
     autotune = e ? atoi(e) : 1;
-    e = getenv("UOC_CONV_CFG");
-    pin_cfg = e ? atoi(e) : -1;
-    e = getenv("UOC_CONV_GLDS");
-    pin_glds = e ? atoi(e) : -1;
     tune_cache_load();
   }
+  const int pin_cfg = UOC_DEV_KNOB("UOC_CONV_CFG", -1);
+#ifdef UOC_DEV
+  const int pin_glds = UOC_DEV_KNOB("UOC_CONV_GLDS", -1);
+#else
+  const int pin_glds = 1;   // one kernel family: the tuner only chooses the tile
+#endif
   Choice stat = {pick_cfg(p), pin_glds >= 0 ? pin_glds : glds_default};
   if (!autotune || pin_cfg >= 0) return stat;
   const TuneKey key = {p.G, p.B, p.H, p.W, p.Cin, p.Cout, p.KH, p.stride, p.dil};
@@ -805,22 +809,60 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   UOC_REQUIRE(p.G >= 1 && p.B >= 1 && p.H >= 1 && p.W >= 1, "conv: bad shape");
   UOC_REQUIRE((long)p.B * p.H * p.W * p.Cin < (1l << 31) && (long)p.B * p.Ho * p.Wo * p.Cout < (1l << 31),
               "conv: tensor too large for 32-bit indexing");
-  static int use_glds = -1;
-  if (use_glds < 0) {
-    const char *e = getenv("UOC_CONV_GLDS");  // 0 = register-staged kernel (kept for A/B measurements)
-    use_glds = e ? atoi(e) : 1;
-  }
+  const int use_glds = UOC_DEV_KNOB("UOC_CONV_GLDS", 1) != 0;  // dev A/B: 0 = the register-staged kernel
   if (p.stem) {
     UOC_REQUIRE(p.Cin == 4 && p.KH == 7 && p.KW == 7 && p.stride == 2 && p.pad == 3 && p.dil == 1 && p.Cout == 64,
                 "conv: stem path is 7x7 s2 p3, NHWC4 -> 64 only");
-    if (use_glds) return launch_glds<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
-    return launch_cfg<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
+#ifdef UOC_DEV
+    if (!use_glds) return launch_cfg<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
+#endif
+    return launch_glds<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
   }
   UOC_REQUIRE(p.Cin % BK == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, BK);
-  // the LDS-DMA kernel addresses a group's input through a 32-bit buffer offset: beyond 2 GB per group the register-staged
-  // kernel (64-bit addresses) runs instead
-  const bool glds_ok = (size_t)p.B * p.H * p.W * p.Cin * 4 + (size_t)(p.pad * p.W + p.pad) * p.Cin * 4 < (1ull << 31);
   UOC_REQUIRE(p.Cout % 64 == 0, "conv: Cout=%d must be a multiple of 64", p.Cout);
+  // the LDS-DMA kernel addresses a group's input through a 32-bit buffer offset: a batch beyond 2 GB per group runs as two
+  // launches over halves of the batch (an output pixel never depends on another image: bit-identical)
+  const size_t halo = (size_t)(p.pad * p.W + p.pad) * p.Cin * 4;
+  static EnvInt limit_mb("UOC_SPLIT_MAX_MB", 0);   // tests: a smaller limit, to exercise the split on small batches (same results)
+  const size_t limit = limit_mb.get() > 0 ? (size_t)limit_mb.get() << 20 : (1ull << 31);
+  const bool glds_ok = (size_t)p.B * p.H * p.W * p.Cin * 4 + halo < limit;
+  if (!glds_ok) {
+    UOC_REQUIRE(p.B > 1 || limit_mb.get() > 0, "conv: one image's input exceeds the 2 GB a 32-bit buffer offset addresses");
+    if (p.B == 1) {   // (only reachable with the test limit) a single image per group: one launch per group
+      ConvParams q = p;
+      for (int g = 0; g < p.G; ++g) {
+        q.G = 1;
+        q.in = p.in + (size_t)g * p.H * p.W * p.Cin;
+        q.out = p.out + (size_t)g * p.Ho * p.Wo * p.Cout;
+        if (p.res) q.res = p.res + (size_t)g * p.Ho * p.Wo * p.Cout;
+        q.w = p.w + (size_t)g * p.KH * p.KW * p.Cout * p.Cin;
+        if (p.bias) q.bias = p.bias + (size_t)g * p.Cout;
+        const Choice ch1 = choose(q, st, use_glds);
+        if (ch1.cfg < 0) {
+          set_error("conv: no tile configuration for Cout=%d", p.Cout);
+          return UOC_EINVAL;
+        }
+        if (int rc = launch_choice(q, st, ch1)) return rc;
+      }
+      return UOC_OK;
+    }
+    // groups are strided by the FULL batch: a slice keeps the group stride only if it is addressed per group
+    for (int g = 0; g < p.G; ++g)
+      for (int b0 = 0; b0 < p.B;) {
+        ConvParams q = p;
+        q.G = 1;
+        q.B = (p.B + 1) / 2 < p.B - b0 ? (p.B + 1) / 2 : p.B - b0;
+        const size_t ii = ((size_t)g * p.B + b0) * p.H * p.W * p.Cin, oo = ((size_t)g * p.B + b0) * p.Ho * p.Wo * p.Cout;
+        q.in = p.in + ii;
+        q.out = p.out + oo;
+        if (p.res) q.res = p.res + oo;
+        q.w = p.w + (size_t)g * p.KH * p.KW * p.Cout * p.Cin;
+        if (p.bias) q.bias = p.bias + (size_t)g * p.Cout;
+        if (int rc = launch_conv(q, st)) return rc;
+        b0 += q.B;
+      }
+    return UOC_OK;
+  }
 #ifdef UOC_DEV   // timing ablations (WRONG results): compiled only into development builds
   static int variant = -1;
   if (variant < 0) {
@@ -838,7 +880,7 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
     return launch_cfg<160, 128, 2, 4, false, 3>(p, st, KC_CONV_160x128);
   }
 #endif
-  const Choice ch = glds_ok ? choose(p, st, use_glds) : Choice{pick_cfg(p), 0};
+  const Choice ch = choose(p, st, use_glds);
   if (ch.cfg < 0) {
     set_error("conv: no tile configuration for Cout=%d", p.Cout);
     return UOC_EINVAL;

@@ -1150,15 +1150,7 @@ struct MsWorkspace {
 
 // UOC_HC_VARIANT: 2 (default) = register-resident kernel, one wave per SIMD; 0 = LDS-fragment kernel (the only one for
 // 128-d fields).  (1 was round 2's two-waves-per-SIMD experiment, measured equal and removed: DESIGN.md.)
-static int hc_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char *e = getenv("UOC_HC_VARIANT");
-    v = e ? atoi(e) : 2;
-    if (v != 0) v = 2;
-  }
-  return v;
-}
+static int hc_variant() { return UOC_DEV_KNOB("UOC_HC_VARIANT", 2) != 0 ? 2 : 0; }   // dev A/B only: the two kernels sum in different orders
 
 // Virtual blocks of a hill-climbing launch: a function of the field size ONLY (about 16 pixel tiles per wave, at most 256
 // blocks of 4 waves), so the fp32 summation order of the new seed positions is the same whether a field is clustered
@@ -1166,11 +1158,8 @@ static int hc_variant() {
 // map could then depend on its launch-set mates.)
 static int hc_virtual_blocks(int n) {
   const int ntile = (n + 15) / 16;
-  static int tiles_per_wave = 0;
-  if (!tiles_per_wave) {
-    const char *e = getenv("UOC_HC_VB_TILES");   // dev (changes the summation order, i.e. the last bits of the seeds): pixel tiles per wave and virtual block
-    tiles_per_wave = e && atoi(e) > 0 ? atoi(e) : 16;
-  }
+  // dev knob (changes the summation order, i.e. the last bits of the seeds): pixel tiles per wave and virtual block
+  const int tiles_per_wave = UOC_DEV_KNOB("UOC_HC_VB_TILES", 16) > 0 ? UOC_DEV_KNOB("UOC_HC_VB_TILES", 16) : 16;
   int nvb = (ntile + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
   if (nvb > 256) nvb = 256;
   if (nvb < 1) nvb = 1;
@@ -1180,11 +1169,7 @@ static int hc_virtual_blocks(int n) {
 // Physical blocks per field: the count p that minimises (rounds of CUs the grid needs) x (virtual blocks per physical
 // block); one 4-wave block per CU (register-resident kernel) or two (LDS-fragment kernel).
 static int hc_physical_blocks(int batch, int nvb, int per_cu) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char *e = getenv("UOC_HC_BLOCKS");   // dev: physical blocks per field
-    forced = e ? atoi(e) : 0;
-  }
+  const int forced = UOC_DEV_KNOB("UOC_HC_BLOCKS", 0);   // dev: physical blocks per field
   if (forced > 0) return forced < nvb ? forced : nvb;
   const int slots = (device_num_cu() > 0 ? device_num_cu() : 256) * per_cu;
   int best = 1;
@@ -1278,11 +1263,7 @@ static int fps_persistent_plan(int batch, int n, int *bpi, int *nslots) {
   // 200 CUs).  The kernel is bound by the per-step grid exchange, not by its 64 FMAs per pixel, and the CUs it does not
   // occupy run other streams' kernels meanwhile: 150.0 -> 158.3 frames/s sustained (round 3; UOC_FPS_PACK=0 restores
   // the spread-out grid, 2 / 3 = at least that many pixels per lane).
-  static int pack = -1;
-  if (pack < 0) {
-    const char *e = getenv("UOC_FPS_PACK");
-    pack = e ? atoi(e) : FPP_SLOTS;
-  }
+  const int pack = UOC_DEV_KNOB("UOC_FPS_PACK", FPP_SLOTS);
   if (pack > ns) ns = pack < FPP_SLOTS ? pack : FPP_SLOTS;
   b = (n + FPP_THREADS * ns - 1) / (FPP_THREADS * ns);  // drop blocks that would own no pixel
   *bpi = b;
@@ -1307,15 +1288,8 @@ static FpsChain &fps_chain() {
   static FpsChain *c = new FpsChain();  // never destructed: static destruction order vs. the HIP runtime is undefined
   return *c;
 }
-// UOC_FPS_COOP=0: plain launch of the persistent grid (co-residency then rests on the plan + the event chain alone)
-static bool fps_cooperative() {
-  static int coop = -1;
-  if (coop < 0) {
-    const char *e = getenv("UOC_FPS_COOP");
-    coop = e ? atoi(e) : 1;
-  }
-  return coop != 0;
-}
+// dev knob UOC_FPS_COOP=0: plain launch of the persistent grid (co-residency then rests on the plan + the event chain alone)
+static bool fps_cooperative() { return UOC_DEV_KNOB("UOC_FPS_COOP", 1) != 0; }
 
 static int run_select_seeds(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
                             int32_t *indices, const MsWorkspace &w, hipStream_t st) {
@@ -1340,7 +1314,7 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
     UOC_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int), st));
     // the LDS pixel slot is only touched when a lane owns more than FPP_RS pixels; without it the kernel needs no
     // dynamic LDS at all and can share a CU with another stream's convolution blocks (two frames in flight)
-    static const bool lds_always = getenv("UOC_FPS_LDS_ALWAYS") != nullptr;  // dev: the round-1 launch shape
+    const bool lds_always = UOC_DEV_KNOB("UOC_FPS_LDS_ALWAYS", 0) != 0;  // dev: the round-1 launch shape
     const size_t lds = (nslots > FPP_RS || lds_always) ? (size_t)FPP_LS * (C / 4) * FPP_THREADS * sizeof(float4) : 0;
     static DeviceOnce attr_set;
     if (!attr_set.done()) {
@@ -1462,11 +1436,7 @@ static void launch_hc(const float *X, int batch, int n, float *Z, int m, float k
           else
 #endif
           {
-            static int quad_ok = -1;
-            if (quad_ok < 0) {
-              const char *e = getenv("UOC_HC_QUAD");   // A/B: 0 = the last seed tile as a padded 16-seed tile (rounds 2-3a)
-              quad_ok = e ? atoi(e) : 1;
-            }
+            const int quad_ok = UOC_DEV_KNOB("UOC_HC_QUAD", 1);   // dev A/B: 0 = the last seed tile as a padded 16-seed tile (rounds 2-3a)
             const int last = m - 16 * (ST - 1);      // seeds in the last tile
             if (quad_ok && ST >= 2 && last >= 1 && last <= 4) {
               static DeviceOnce attr_q;

@@ -9,6 +9,7 @@
 //   resnet.py:116-270              stem 7x7 s2 + BN + ReLU + maxpool; layers [3,4,6,3] of BasicBlocks;
 //                                  :188-234 stride->dilation once the stride reaches 8 (layer3 d=2, layer4 d=4)
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -23,7 +24,9 @@ struct ConvLayer {
   int Cin, Cout, K, stride, dil, pad, relu;
   bool has_bn, has_bias, stem;
   float *d_w = nullptr, *d_b = nullptr;  // [G][...]
-  float *d_U = nullptr;                  // Winograd F(2x2) weights [G][16][Cin/32][Cout][32] (eligible layers, wino_f == 2)
+#ifdef UOC_DEV
+  float *d_U = nullptr;                  // Winograd F(2x2) weights [G][16][Cin/32][Cout][32] (eligible layers, wino_f == 2; dev builds)
+#endif
   float *d_U4 = nullptr;                 // Winograd F(4x4) weights [G*36][Cout][Cin] (eligible layers, wino_f == 4)
   size_t w_per_group = 0;
 };
@@ -41,8 +44,11 @@ struct uoc_net {
   int stem = -1, fc = -1;
   bool finalized = false;
   int device = -1;
+  // Which layers run as Winograd convolutions is a compile-time rule of the shipped library (the algorithms round
+  // differently; no environment variable may change a result).  Development builds can set both (UOC_WINOGRAD_MIN_CIN,
+  // UOC_WINOGRAD_F) for A/B measurements.
   int wino_min_cin = 64;   // 3x3 stride-1 layers with Cin >= this run as Winograd convolutions; 0 = never (round 4: 64, was 128)
-  int wino_f = 4;          // output tile of the Winograd path: 4 = F(4x4,3x3) (csrc/wino4.hip), 2 = F(2x2,3x3) (csrc/wino.hip)
+  int wino_f = 4;          // output tile of the Winograd path: 4 = F(4x4,3x3) (csrc/wino4.hip), 2 = F(2x2,3x3) (csrc/wino.hip, dev)
   int mode = UOC_NET_RGBD_ADD;
   int G = 2;  // backbones evaluated side by side (2 for RGBD 'add' and 'cat')
 };
@@ -179,10 +185,13 @@ static int finalize_layer(uoc_net *n, ConvLayer &L) {
     } else if (n->wino_f == 4) {
       UOC_HIP_CHECK(hipMalloc(&L.d_U4, (size_t)G * 36 * L.Cout * L.Cin * sizeof(float)));
       if (int rc = launch_wino4_weights(L.d_w, L.d_U4, G, L.Cout, L.Cin, nullptr)) return rc;
-    } else {
+    }
+#ifdef UOC_DEV
+    else {
       UOC_HIP_CHECK(hipMalloc(&L.d_U, (size_t)G * 16 * L.Cout * L.Cin * sizeof(float)));
       if (int rc = launch_wino_weights(L.d_w, L.d_U, G, L.Cout, L.Cin, nullptr)) return rc;
     }
+#endif
     UOC_HIP_CHECK(hipDeviceSynchronize());
   }
   return UOC_OK;
@@ -204,7 +213,6 @@ static Dims dims(int H, int W) {
 
 struct NetWs {
   float *in4, *stem, *stem_part, *buf[4], *fc, *wino;
-  size_t wino_half;   // F(4x4): floats per half of `wino` (V planes | M planes)
   size_t total;
 };
 static NetWs carve_net(void *base, int mode, int wino_f, int B, int H, int W) {
@@ -226,16 +234,20 @@ static NetWs carve_net(void *base, int mode, int wino_f, int B, int H, int W) {
   if (a3 > act) act = a3;
   for (int i = 0; i < 4; ++i) w.buf[i] = take(act);
   w.fc = take((size_t)G * B * d.H3 * d.W3 * 64);
-  // Winograd scratch V[G][16][Cin/32][tiles][32]: worst case over the layers that may use it (1/8 resolution,
-  // dilation 2 with 256 channels or dilation 4 with 512 channels; also sized for 1/4 resolution x 64)
-  size_t wv = wino_v_floats(G, B, d.H3, d.W3, 4, 512);
-  const size_t wv3 = wino_v_floats(G, B, d.H3, d.W3, 2, 256), wv2 = wino_v_floats(G, B, d.H3, d.W3, 1, 128),
-               wv1 = wino_v_floats(G, B, d.H2, d.W2, 1, 64);
-  if (wv3 > wv) wv = wv3;
-  if (wv2 > wv) wv = wv2;
-  if (wv1 > wv) wv = wv1;
+  // Winograd scratch: worst case over the layers that may use it (1/8 resolution, dilation 2 with 256 channels or
+  // dilation 4 with 512 channels; also sized for 1/4 resolution x 64)
+  size_t wv = 0;
+#ifdef UOC_DEV   // F(2x2): V[G][16][Cin/32][tiles][32]
+  if (wino_f != 4) {
+    wv = wino_v_floats(G, B, d.H3, d.W3, 4, 512);
+    const size_t wv3 = wino_v_floats(G, B, d.H3, d.W3, 2, 256), wv2 = wino_v_floats(G, B, d.H3, d.W3, 1, 128),
+                 wv1 = wino_v_floats(G, B, d.H2, d.W2, 1, 64);
+    if (wv3 > wv) wv = wv3;
+    if (wv2 > wv) wv = wv2;
+    if (wv1 > wv) wv = wv1;
+  }
+#endif
   if (wino_f == 4) {  // F(4x4): V and M frequency planes [G*36][tiles][Cin + Cout]
-    wv = 0;
     const int cand[6][4] = {{3, 4, 512, 512}, {3, 4, 256, 512}, {3, 2, 256, 256}, {3, 2, 128, 256}, {3, 1, 128, 128}, {2, 1, 64, 64}};
     for (const auto &c : cand) {
       const size_t v = wino4_ws_floats(G, B, c[0] == 3 ? d.H3 : d.H2, c[0] == 3 ? d.W3 : d.W2, c[1], c[2], c[3]);
@@ -243,7 +255,6 @@ static NetWs carve_net(void *base, int mode, int wino_f, int B, int H, int W) {
     }
   }
   w.wino = take(wv);
-  w.wino_half = wv / 2;
   w.total = off;
   return w;
 }
@@ -277,7 +288,9 @@ static int run_conv(int G, const ConvLayer &L, const float *in, const float *res
                     int Ho, int Wo, hipStream_t st, float *wino_ws = nullptr) {
   const ConvParams p = conv_params(G, L, in, res, out, B, H, W, Ho, Wo);
   if (L.d_U4 && wino_ws && wino4_eligible(p)) return launch_wino4_conv(p, L.d_U4, wino_ws, st);
+#ifdef UOC_DEV
   if (L.d_U && wino_ws && wino_eligible(p)) return launch_wino_conv(p, L.d_U, wino_ws, st);
+#endif
   return launch_conv(p, st);
 }
 
@@ -300,8 +313,8 @@ int uoc_net_create_mode(uoc_net **out, int mode) {
   n->mode = mode;
   n->G = (mode == UOC_NET_RGBD_ADD || mode == UOC_NET_RGBD_CAT) ? 2 : 1;
   build_graph(n);
-  if (const char *e = getenv("UOC_WINOGRAD_MIN_CIN")) n->wino_min_cin = atoi(e);  // 0 disables the Winograd path
-  if (const char *e = getenv("UOC_WINOGRAD_F")) n->wino_f = atoi(e) == 2 ? 2 : 4;     // A/B: the F(2x2,3x3) kernels of round 1-2
+  n->wino_min_cin = UOC_DEV_KNOB("UOC_WINOGRAD_MIN_CIN", 64);          // dev A/B: 0 disables the Winograd path
+  n->wino_f = UOC_DEV_KNOB("UOC_WINOGRAD_F", 4) == 2 ? 2 : 4;           // dev A/B: the F(2x2,3x3) kernels of rounds 1-2
   *out = n;
   return UOC_OK;
 }
@@ -313,7 +326,9 @@ int uoc_net_destroy(uoc_net *n) {
   for (auto &L : n->layers) {
     if (L.d_w) (void)hipFree(L.d_w);
     if (L.d_b) (void)hipFree(L.d_b);
+#ifdef UOC_DEV
     if (L.d_U) (void)hipFree(L.d_U);
+#endif
     if (L.d_U4) (void)hipFree(L.d_U4);
   }
   delete n;
@@ -379,69 +394,33 @@ int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, i
   }
   if (int rc = launch_maxpool3x3s2(w.stem, w.buf[0], G * B, d.H1, d.W1, 64, d.H2, d.W2, st)) return rc;
 
-  // Consecutive F(4x4) layers form a chain: the M planes of a layer stay "pending" until the next step decides how they
-  // are turned into activations — fused with the next layer's input transform (wino4_chain_mid: same geometry, the NHWC
-  // tensor is written only if somebody else reads it), or by the plain output transform.
-  float *Vp = w.wino, *Mp = w.wino ? w.wino + w.wino_half : nullptr;
-  bool pending = false;
-  ConvParams pend;
-  auto flush = [&]() -> int {   // the pending layer's output transform on its own
-    if (!pending) return UOC_OK;
-    pending = false;
-    return wino4_chain_output(pend, Mp, st);
-  };
-  // one convolution of the chain; `keep_y`: if it is fused INTO (its input is the pending layer's output), must that
-  // output also exist as an NHWC tensor (a residual or a 1x1 shortcut reads it)?
-  auto conv_step = [&](const ConvLayer &L, const float *in, const float *res, float *out, int h_, int w_, int ho_, int wo_,
-                       bool keep_y) -> int {
-    const ConvParams p = conv_params(G, L, in, res, out, B, h_, w_, ho_, wo_);
-    if (L.d_U4 && Vp && wino4_chain_ok(p)) {
-      if (pending && pend.out == in && wino4_can_fuse(pend, p)) {
-        if (int rc = wino4_chain_mid(pend, keep_y, Mp, Vp, st)) return rc;
-        pending = false;
-      } else {
-        if (int rc = flush()) return rc;
-        if (int rc = wino4_chain_input(p, Vp, st)) return rc;
-      }
-      if (wino4_small_ok(p)) return wino4_chain_gemm_out(p, L.d_U4, Vp, st);   // small K: GEMMs + output transform in one kernel
-      if (int rc = wino4_chain_gemm(p, L.d_U4, Vp, Mp, st)) return rc;
-      pend = p;
-      pending = true;
-      return UOC_OK;
-    }
-    if (int rc = flush()) return rc;
-    return run_conv(G, L, in, res, out, B, h_, w_, ho_, wo_, st, w.wino);
-  };
   int cur = 0, h = d.H2, wd = d.W2;
   for (const Block &b : n->blocks) {
     const ConvLayer &c1 = n->layers[b.conv1], &c2 = n->layers[b.conv2];
     const int ho = (h - 1) / c1.stride + 1, wo = (wd - 1) / c1.stride + 1;
     float *x = w.buf[cur], *tmp = w.buf[(cur + 1) & 3], *sc = w.buf[(cur + 2) & 3], *y = w.buf[(cur + 3) & 3];
-    // the block input x (= the previous block's output) is always needed as a tensor: residual or shortcut input
-    if (int rc = conv_step(c1, x, nullptr, tmp, h, wd, ho, wo, true)) return rc;
+    if (int rc = run_conv(G, c1, x, nullptr, tmp, B, h, wd, ho, wo, st, w.wino)) return rc;
     const float *res = x;
-    if (b.down >= 0) {
-      // the 1x1 shortcut reads x; x is complete by now (the fused step above wrote it, or flush() did)
+    if (b.down >= 0) {   // 1x1 (possibly strided) shortcut + BN (resnet.py:215-219)
       if (int rc = run_conv(G, n->layers[b.down], x, nullptr, sc, B, h, wd, ho, wo, st)) return rc;
       res = sc;
     }
-    // conv1's output feeds conv2 only: when fused, the NHWC tensor `tmp` is never written
-    if (int rc = conv_step(c2, tmp, res, y, ho, wo, ho, wo, false)) return rc;
+    if (int rc = run_conv(G, c2, tmp, res, y, B, ho, wo, ho, wo, st, w.wino)) return rc;
     cur = (cur + 3) & 3;
     h = ho;
     wd = wo;
   }
-  if (int rc = flush()) return rc;
   if (int rc = run_conv(G, n->layers[n->fc], w.buf[cur], nullptr, w.fc, B, h, wd, h, wd, st)) return rc;
   return launch_head(w.fc, G == 2 ? w.fc + (size_t)B * h * wd * 64 : nullptr, d_embed, B, h, wd, H, W,
                      n->mode == UOC_NET_RGBD_CAT, st);
 }
 
 /* Generic NHWC convolution entry (unit tests / integration): G independent groups stacked on the
- * leading dimension; per group: weights [T][Cout][Cin] with BN folded. */
-int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, const float *d_res, float *d_out, int G,
-                    int B, int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu,
-                    void *stream) {
+ * leading dimension; per group: weights [T][Cout][Cin] with BN folded.  `algo` names the algorithm; nothing in the
+ * environment decides it. */
+int uoc_conv2d_nhwc_algo(const float *d_in, const float *d_w, const float *d_bias, const float *d_res, float *d_out, int G,
+                         int B, int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu, int algo,
+                         void *stream) {
   UOC_REQUIRE(K == 1 || K == 3, "K=%d (only 1 or 3)", K);
   UOC_REQUIRE(d_res == nullptr || d_res != d_out, "conv2d: the residual must not alias the output");
   ConvParams p;
@@ -465,54 +444,60 @@ int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, co
   p.stem = 0;
   p.Ho = (H + 2 * pad - dil * (K - 1) - 1) / stride + 1;
   p.Wo = (W + 2 * pad - dil * (K - 1) - 1) / stride + 1;
-  static EnvInt force_env("UOC_CONV_WINOGRAD", 0);  // test / micro-benchmark hook: 1 = Winograd F(2x2), 4 = F(4x4) for eligible shapes (cached: uoc_reload_env)
-  const int force = force_env.get();
-  if (force == 4 && wino4_eligible(p)) {
+  hipStream_t st = (hipStream_t)stream;
+  if (algo == UOC_CONV_DIRECT) return launch_conv(p, st);
+  // scratch owned by this entry (kept between calls, grown on demand; the network path gets its scratch from the caller):
+  // one caller thread at a time, as the header says — the mutex makes a violation slow instead of wrong
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (algo == UOC_CONV_WINOGRAD4) {
+    UOC_REQUIRE(wino4_eligible(p), "conv2d: shape not eligible for Winograd F(4x4,3x3)");
     static float *U4 = nullptr, *ws4 = nullptr;
     static size_t ucap4 = 0, wcap4 = 0;
-    static const float *u4_for = nullptr;
     const size_t un = (size_t)G * 36 * Cout * Cin, wn = wino4_ws_floats(G, B, H, W, dil, Cin, Cout);
-    hipStream_t st = (hipStream_t)stream;
     if (un > ucap4) {
       if (U4) (void)hipFree(U4);
       UOC_HIP_CHECK(hipMalloc(&U4, un * sizeof(float)));
       ucap4 = un;
-      u4_for = nullptr;
     }
     if (wn > wcap4) {
       if (ws4) (void)hipFree(ws4);
       UOC_HIP_CHECK(hipMalloc(&ws4, wn * sizeof(float)));
       wcap4 = wn;
     }
-    (void)u4_for;   // always re-transform: callers reuse device addresses with new weights
+    // always re-transform: callers reuse device addresses with new weights
     if (int rc = launch_wino4_weights(d_w, U4, G, Cout, Cin, st)) return rc;
     return launch_wino4_conv(p, U4, ws4, st);
   }
-  if (force == 1 && wino_eligible(p)) {
-    // scratch owned by this entry (kept between calls; the network path gets its scratch from the caller)
+#ifdef UOC_DEV
+  if (algo == UOC_CONV_WINOGRAD2) {
+    UOC_REQUIRE(wino_eligible(p), "conv2d: shape not eligible for Winograd F(2x2,3x3)");
     static float *U = nullptr, *V = nullptr;
     static size_t ucap = 0, vcap = 0;
-    static const float *u_for = nullptr;
     const size_t un = (size_t)G * 16 * Cout * Cin, vn = wino_v_floats(G, B, H, W, dil, Cin);
-    hipStream_t st = (hipStream_t)stream;
     if (un > ucap) {
       if (U) (void)hipFree(U);
       UOC_HIP_CHECK(hipMalloc(&U, un * sizeof(float)));
       ucap = un;
-      u_for = nullptr;
     }
     if (vn > vcap) {
       if (V) (void)hipFree(V);
       UOC_HIP_CHECK(hipMalloc(&V, vn * sizeof(float)));
       vcap = vn;
     }
-    if (u_for != d_w) {
-      if (int rc = launch_wino_weights(d_w, U, G, Cout, Cin, st)) return rc;
-      u_for = d_w;
-    }
+    if (int rc = launch_wino_weights(d_w, U, G, Cout, Cin, st)) return rc;
     return launch_wino_conv(p, U, V, st);
   }
-  return launch_conv(p, (hipStream_t)stream);
+#endif
+  set_error("conv2d: unknown algorithm %d", algo);
+  return UOC_EINVAL;
+}
+
+int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, const float *d_res, float *d_out, int G,
+                    int B, int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu,
+                    void *stream) {
+  return uoc_conv2d_nhwc_algo(d_in, d_w, d_bias, d_res, d_out, G, B, H, W, Cin, Cout, K, stride, dil, pad, relu,
+                              UOC_CONV_DIRECT, stream);
 }
 
 }  // extern "C"

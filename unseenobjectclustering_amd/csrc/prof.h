@@ -31,8 +31,6 @@ enum KernelClass {
   KC_WINO4_INPUT,
   KC_WINO4_GEMM,
   KC_WINO4_OUTPUT,
-  KC_WINO4_MID,   // output transform of one layer fused with the input transform of the next
-  KC_WINO4_SMALL, // plane GEMMs + output transform of a small-K layer in one kernel
   KC_COUNT
 };
 

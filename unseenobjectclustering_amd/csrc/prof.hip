@@ -17,7 +17,7 @@ static const char *kNames[KC_COUNT] = {
     "wino_input",        "wino_gemm",
     "net_misc",          "head",             "fps_step",         "hc_iter",         "hc_finalize",
     "seed_cc",           "assign",           "relabel",          "roi",
-    "wino4_input",       "wino4_gemm",       "wino4_output",    "wino4_mid",       "wino4_small"};
+    "wino4_input",       "wino4_gemm",       "wino4_output"};
 
 struct Rec {
   int kc;

@@ -18,6 +18,9 @@
 //     of A^T (.) A^T.  The two groups' partial outputs meet once in LDS; bias, residual and ReLU are
 //     applied in the epilogue.  Operand staging is the LDS-DMA ring of csrc/conv.hip (3 stages, two
 //     chunks ahead, counted vmcnt, source-side XOR swizzle, zero page).
+// DEVELOPMENT BUILDS ONLY (-DUOC_DEV): the shipped library runs every eligible layer as F(4x4,3x3) (csrc/wino4.hip) since
+// round 3; these kernels stay as the measured A/B alternative (profiles/r03_ab_winograd_f{2,4}.json).
+#ifdef UOC_DEV
 #include "conv.h"
 #include "prof.h"
 
@@ -521,3 +524,5 @@ int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_
 }
 
 }  // namespace uoc
+
+#endif  // UOC_DEV

@@ -26,6 +26,9 @@
 namespace uoc {
 
 constexpr int W4BK = 32;  // cin chunk (floats): one 128-byte row piece per DMA lane group
+#ifndef W4_DEFAULT_WAVES
+#define W4_DEFAULT_WAVES 8   // waves per plane-GEMM block on the 128-wide tiles (see wino4_gemm_kernel)
+#endif
 
 // ---- elementwise kernels: thin grid-stride wrappers around the bodies in wino4_math.h ---------------------------
 __global__ __launch_bounds__(256) void wino4_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int G,
@@ -67,89 +70,6 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
 }
 
 
-// ---- output transform of layer L fused with the input transform of layer L+1 (same geometry) --------------------------
-// Inside a chain of Winograd layers of one resolution and dilation the NHWC activation between two layers is only ever
-// read back as 6x6 patches.  One block owns one dilation-phase image of one (group, image) and CS channels: it turns the
-// phase image's M tiles into outputs (A^T M A + bias (+ residual), ReLU: wino4_math.h, the very functions of the two
-// separate kernels, so the results are bit-identical), keeps them in LDS with the one-pixel zero frame the next
-// convolution's padding asks for, and transforms the 6x6 patches straight into the next layer's V planes.  A phase image
-// has no neighbours (its halo is padding), so no tile is computed twice.  The activation itself is written to HBM only
-// when somebody else needs it (the next block's residual): per pair of layers 4.5 instead of 6.5-7.75 activation sizes
-// move.  Layout of the LDS image: [(4 TH + 2) rows][(4 TW + 2) columns][CS / 4] float4.
-template <int VEC>
-__global__ __launch_bounds__(VEC == 4 ? 256 : 512) void wino4_mid_kernel(const float *__restrict__ M, const float *__restrict__ bias,
-                                                        const float *__restrict__ res, float *__restrict__ yout,
-                                                        float *__restrict__ V, Wino4Geom geo, int G, int C, int relu, int CS,
-                                                        int sib, int units) {
-  typedef typename W4Vec<VEC>::type T;
-  extern __shared__ __attribute__((aligned(16))) float ysm_raw[];
-  T *ysm = reinterpret_cast<T *>(ysm_raw);
-  const int Q = CS / VEC, slices = C / CS;
-  const int Wl = 4 * geo.TW + 2, Hl = 4 * geo.TH + 2;
-  // blocks are dealt to the 8 XCDs round-robin; `sib` sibling slices share 128-byte lines of M and V, so they are
-  // mapped to consecutive blocks of ONE XCD (one L2 fetches the line once)
-  const int x8 = blockIdx.x & 7, j8 = blockIdx.x >> 3;
-  const int unit = ((j8 / sib) * 8 + x8) * sib + j8 % sib;
-  if (unit >= units) return;
-  const int slice = unit % slices;
-  int u = unit / slices;
-  const int px = u % geo.d;
-  u /= geo.d;
-  const int py = u % geo.d;
-  u /= geo.d;
-  const int b = u % geo.B, g = u / geo.B;
-  const int ntile = geo.TH * geo.TW, items = ntile * Q;
-  const int tile0 = ((b * geo.d + py) * geo.d + px) * ntile;
-  const size_t plane = (size_t)geo.NT * C;
-  const size_t gsz = (size_t)geo.Bg * geo.H * geo.W * C;
-  const int tid = threadIdx.x, nthr = blockDim.x;
-
-  for (int i = tid; i < Hl * Wl * Q; i += nthr) w4_zero(ysm[i]);
-  __syncthreads();
-  for (int it = tid; it < items; it += nthr) {
-    const int cq = it % Q, t = it / Q, ty = t / geo.TW, tx = t - ty * geo.TW;
-    const int ch = slice * CS + VEC * cq;
-    const float *src = M + (size_t)g * 36 * plane + (size_t)(tile0 + t) * C + ch;
-    T m[36];
-#pragma unroll
-    for (int k = 0; k < 36; ++k) m[k] = *reinterpret_cast<const T *>(src + (size_t)k * plane);
-    T yv[4][4];
-    wino4_output_tile(m, yv);
-    T bv;
-    if (bias)
-      bv = *reinterpret_cast<const T *>(bias + (size_t)g * C + ch);
-    else
-      w4_zero(bv);
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int y = py + (4 * ty + a) * geo.d;
-      if (y >= geo.H) continue;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int x = px + (4 * tx + e) * geo.d;
-        if (x >= geo.W) continue;
-        const size_t o = (size_t)g * gsz + (((size_t)b * geo.H + y) * geo.W + x) * C + ch;
-        const T v = wino4_epilogue(yv[a][e], bv, res ? res + o : nullptr, relu);
-        ysm[((4 * ty + a + 1) * Wl + 4 * tx + e + 1) * Q + cq] = v;
-        if (yout) *reinterpret_cast<T *>(yout + o) = v;
-      }
-    }
-  }
-  __syncthreads();
-  for (int it = tid; it < items; it += nthr) {
-    const int cq = it % Q, t = it / Q, ty = t / geo.TW, tx = t - ty * geo.TW;
-    T d[6][6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) d[i][j] = ysm[((4 * ty + i) * Wl + 4 * tx + j) * Q + cq];
-    T v[36];
-    wino4_input_tile(d, v);
-    float *dst = V + (size_t)g * 36 * plane + (size_t)(tile0 + t) * C + slice * CS + VEC * cq;
-#pragma unroll
-    for (int k = 0; k < 36; ++k) *reinterpret_cast<T *>(dst + (size_t)k * plane) = v[k];
-  }
-}
 
 // ---- the batched GEMM over (group, frequency) planes -------------------------------------------------------------
 __device__ __forceinline__ f32x4 w4mfma(float a, float b, f32x4 c) {
@@ -177,106 +97,31 @@ __device__ __forceinline__ void w4_wait_vmcnt() {
   if (UOC_W4_ABLATE != 2) wait_vmcnt<N>();
 }
 
-// ---- small-K layers (Cin = Cout = 64 / 128): plane GEMMs + output transform in ONE kernel, no M planes -------------------
-// With K = 64 a plane GEMM does 32 flop per byte of V + M: the layer is HBM-bound and M (2.25 x the activation, written by
-// the GEMM and read back by the output transform) is 40 % of its traffic.  Here a block owns 16 tiles x all output channels
-// and walks the 36 planes of its branch: wave w owns output channels 16 w .. 16 w + 15 and keeps ALL 36 plane accumulators
-// of its 16 x 16 tile in registers (144 VGPRs), so that after the last plane every lane holds the 36 frequencies of its
-// (tile, 4 channels) and applies A^T . A, bias, residual and ReLU itself (wino4_math.h: the functions of the separate
-// kernels; MFMA order per accumulator = cin order as in the plane GEMM: bit-identical results).  Operands go straight
-// from L2 into registers (one plane ahead), no LDS: U (36 x C x C floats per branch, 0.6 / 2.4 MB) is re-read per 16
-// tiles from L2 instead of M making a round trip through HBM.
-template <int C>
-__global__ __launch_bounds__(C * 4) __attribute__((amdgpu_waves_per_eu(2))) void wino4_small_kernel(const float *__restrict__ V, const float *__restrict__ U,
-                                                            const float *__restrict__ bias, const float *__restrict__ res,
-                                                            float *__restrict__ out, Wino4Geom geo, int G, int relu) {
-  constexpr int KK = C / 16;   // float4 loads per operand row and plane (16 K-steps of 4 per load quartet)
-  const int rtiles = (geo.NT + 15) >> 4;
-  const int g = blockIdx.x / rtiles, rt = blockIdx.x - g * rtiles;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int t = lane & 15, q = lane >> 4;
-  const int row = min(rt * 16 + t, geo.NT - 1);   // rows beyond the last tile read the last valid row, never stored
-  const size_t plane_v = (size_t)geo.NT * C, plane_u = (size_t)C * C;
-  const float *vp = V + (size_t)g * 36 * plane_v + (size_t)row * C + 4 * q;
-  const float *up = U + (size_t)g * 36 * plane_u + (size_t)(16 * wave + t) * C + 4 * q;
-  f32x4 acc[36];
-  float4 wf[KK], xf[KK], wn[KK], xn[KK];
-#pragma unroll
-  for (int kk = 0; kk < KK; ++kk) {
-    wf[kk] = *reinterpret_cast<const float4 *>(up + 16 * kk);
-    xf[kk] = *reinterpret_cast<const float4 *>(vp + 16 * kk);
-  }
-#pragma unroll
-  for (int xi = 0; xi < 36; ++xi) {
-    if (xi + 1 < 36) {
-#pragma unroll
-      for (int kk = 0; kk < KK; ++kk) {
-        wn[kk] = *reinterpret_cast<const float4 *>(up + (size_t)(xi + 1) * plane_u + 16 * kk);
-        xn[kk] = *reinterpret_cast<const float4 *>(vp + (size_t)(xi + 1) * plane_v + 16 * kk);
-      }
-    }
-    f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      a = w4mfma(wf[kk].x, xf[kk].x, a);
-      a = w4mfma(wf[kk].y, xf[kk].y, a);
-      a = w4mfma(wf[kk].z, xf[kk].z, a);
-      a = w4mfma(wf[kk].w, xf[kk].w, a);
-    }
-    acc[xi] = a;
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      wf[kk] = wn[kk];
-      xf[kk] = xn[kk];
-    }
-  }
-  const int tau = rt * 16 + t;
-  if (tau >= geo.NT) return;
-  float4 m[36];
-#pragma unroll
-  for (int k = 0; k < 36; ++k) m[k] = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
-  float4 yv[4][4];
-  wino4_output_tile(m, yv);
-  int b, oy, ox;
-  wino4_decode(tau, geo, b, oy, ox);
-  const int ch = 16 * wave + 4 * q;
-  const size_t gsz = (size_t)geo.Bg * geo.H * geo.W * C;
-  float4 bv;
-  if (bias)
-    bv = *reinterpret_cast<const float4 *>(bias + (size_t)g * C + ch);
-  else
-    w4_zero(bv);
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int y = oy + a * geo.d;
-    if (y >= geo.H) continue;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int x = ox + e * geo.d;
-      if (x >= geo.W) continue;
-      const size_t o = (size_t)g * gsz + (((size_t)b * geo.H + y) * geo.W + x) * C + ch;
-      *reinterpret_cast<float4 *>(out + o) = wino4_epilogue(yv[a][e], bv, res ? res + o : nullptr, relu);
-    }
-  }
-}
-
 // PAIR (round 4): a 4-stage ring and ONE barrier per TWO K-chunks.  The barrier costs 5-9 % of the kernel (15 % on 4-chunk
 // items: timing ablation, profiles/r04_pmc_mfma.md); a pair of chunks is fetched two chunks ahead into the two stages the
 // previous pair has just left, so the barrier at the end of a pair covers both hazards (the DMA'd rows of the next pair are
 // visible to every wave; every wave has finished reading the stages the pair after next will overwrite).  The items of a
 // block always hold an even number of chunks (Cin / 32 = 2, 4, 8, 16), so a pair never straddles two items.  Same MFMA
 // order per accumulator as the single-chunk loop: bit-identical results.
-template <int BM, int BN, bool PAIR>
-__global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
-                                                         float *__restrict__ Mo, int NT, int Cin, int Cout, int planes,
-                                                         int mtiles, int nt_shift) {
-  constexpr int WM = BM / 2, WN = BN / 4;
+//
+// NW (round 5): waves per block.  8 = two waves per SIMD as 2 (m) x 4 (n), wave tile (BM/2) x (BN/4) — 0.175 fragment reads
+// per MFMA at 160 x 128.  4 = ONE wave per SIMD as 2 x 2 on the SAME block tile and LDS ring, wave tile (BM/2) x (BN/2) —
+// 80 x 64: (5 + 4) ds_read_b128 per 80 MFMAs = 0.1125 per MFMA (each read's write-back costs ~24 cycles of the fp32 lanes
+// the MFMA runs on, profiles/r02_mfma_microbenchmarks.md) and half as many waves meeting at the barrier.  Same cin order
+// per accumulator: bit-identical.
+template <int BM, int BN, bool PAIR, int NW>
+__global__ __launch_bounds__(NW * 64) void wino4_gemm_kernel(const float *__restrict__ V, const float *__restrict__ U,
+                                                             float *__restrict__ Mo, int NT, int Cin, int Cout, int planes,
+                                                             int mtiles, int nt_shift) {
+  static_assert(NW == 8 || NW == 4, "waves per block");
+  constexpr int WAVES_N = NW / 2;   // 2 (m) x WAVES_N (n)
+  constexpr int WM = BM / 2, WN = BN / WAVES_N;
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr int R = BM + BN;
-  constexpr int RPP = 64;  // rows per DMA pass: 8 waves x 8 rows (1 KiB per wave-instruction)
+  constexpr int RPP = NW * 8;  // rows per DMA pass: every wave moves 8 rows (1 KiB) per instruction
   constexpr int NPA = (BM + RPP - 1) / RPP, NPW = (BN + RPP - 1) / RPP, NPASS = NPA + NPW;
   constexpr int STAGE = R * W4BK;
-  static_assert(WM % 16 == 0 && WN % 16 == 0 && R % 8 == 0 && NPASS <= 8, "tile shape");
+  static_assert(WM % 16 == 0 && WN % 16 == 0 && R % 8 == 0 && NPASS <= 12, "tile shape");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];  // [3 | 4][R][32]
 
@@ -295,7 +140,7 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) char *)smem);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int t = lane & 15, q = lane >> 4;
 
   // The descriptors span ALL planes and no lane ever relies on the range check: measured on gfx950, a descriptor of one
@@ -394,7 +239,7 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
   int cmp_plane = iss_plane, cmp_rem = iss_rem, cmp_cc = 0;
 
   float4 wa0[TN], xb0[TM], wa1[TN], xb1[TM];
-  const bool early = wave < 4;         // waves w and w+4 share a SIMD: they issue their DMA bursts at different points
+  const bool early = NW == 4 || wave < 4;   // NW = 8: waves w and w+4 share a SIMD and issue their DMA bursts at different points
   auto epilogue = [&]() {   // item complete: store its accumulators into the plane, start the next item from zero
     cmp_cc = 0;
     const int mt = cmp_rem >> nt_shift, nt = cmp_rem & (ntiles - 1);
@@ -426,7 +271,7 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
     w4_wait_vmcnt<0>();
     W4_BARRIER();
     W4_FRAG(0, 0, wa0, xb0)
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
     for (int kc = 0; kc < nchunks; kc += 2) {
       const int sa = (kc & 2), sb = sa + 1, sc = sa ^ 2, sd = sc + 1;   // stages of this pair / of the next
       const bool more = kc + 2 < nchunks;
@@ -497,7 +342,7 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
   // MI355X_MICROARCH.md, "Two waves per SIMD", item 4): one static priority bump for it, no per-phase flips.
   // Measured alone: layer4 412 -> 402 us, 28-crop layer4 533 -> 528 us, the short-K shapes unchanged; in the
   // three-stream pipeline neutral (160.9-161.2 frames/s either way, same-box A/B).
-  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+  if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);
   for (int kc = 0; kc < nchunks; ++kc) {
     if (kc + 2 < nchunks && early) W4_ISSUE(s_nn)
     W4_MFMA_E(wa0, xb0, x)
@@ -539,7 +384,7 @@ __global__ __launch_bounds__(512) void wino4_gemm_kernel(const float *__restrict
 #undef W4_MFMA_E
 }
 
-template <int BM, int BN, bool PAIR>
+template <int BM, int BN, bool PAIR, int NW>
 static int launch_wino4_gemm_t(const float *V, const float *U, float *Mo, int NT, int Cin, int Cout, int planes, int nblocks,
                                hipStream_t st) {
   const int mtiles = (NT + BM - 1) / BM, ntiles = Cout / BN;
@@ -552,12 +397,12 @@ static int launch_wino4_gemm_t(const float *V, const float *U, float *Mo, int NT
   UOC_REQUIRE(!PAIR || (Cin / W4BK) % 2 == 0, "winograd F(4x4): the pair loop needs an even number of 32-channel chunks");
   static DeviceOnce attr_set;
   if (!attr_set.done()) {
-    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&wino4_gemm_kernel<BM, BN, PAIR>),
+    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&wino4_gemm_kernel<BM, BN, PAIR, NW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set.mark();
   }
-  hipLaunchKernelGGL((wino4_gemm_kernel<BM, BN, PAIR>), dim3(nblocks), dim3(512), lds, st, V, U, Mo, NT, Cin, Cout, planes, mtiles,
-                     nt_shift);
+  hipLaunchKernelGGL((wino4_gemm_kernel<BM, BN, PAIR, NW>), dim3(nblocks), dim3(NW * 64), lds, st, V, U, Mo, NT, Cin, Cout, planes,
+                     mtiles, nt_shift);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
 }
@@ -596,18 +441,12 @@ static void pick_wino4_tile(int NT, int Cout, int planes, int &bm, int &bn, int 
 static int launch_wino4_gemm(const float *V, const float *U, float *Mo, int NT, int Cin, int Cout, int planes, hipStream_t st) {
   int bm, bn, nblocks;
   pick_wino4_tile(NT, Cout, planes, bm, bn, nblocks);
-  static int env_bm = 0, env_bn = 0, env_seen = -1;   // dev knob UOC_WINO4_TILE="BMxBN", cached (uoc_reload_env re-reads)
-  if (env_seen != g_env_epoch.load(std::memory_order_acquire)) {
-    env_seen = g_env_epoch.load(std::memory_order_acquire);
-    env_bm = env_bn = 0;
-    if (const char *e = getenv("UOC_WINO4_TILE")) {
-      int a = 0, b = 0;
-      if (sscanf(e, "%dx%d", &a, &b) == 2 && (b == 64 || b == 128)) env_bm = a, env_bn = b;
-    }
-  }
-  if (env_bm > 0) {
-    const int a = env_bm, b = env_bn;
-    if (Cout % b == 0) {
+#ifdef UOC_DEV
+  // dev knob UOC_WINO4_TILE = 1000 * BM + BN (e.g. 160128), through the atomic EnvInt cache (uoc_reload_env re-reads)
+  const int env_tile = UOC_DEV_KNOB("UOC_WINO4_TILE", 0);
+  if (env_tile > 0) {
+    const int a = env_tile / 1000, b = env_tile % 1000;
+    if ((b == 64 || b == 128 || b == 256) && Cout % b == 0) {
       bm = a;
       bn = b;
       const int ncu = device_num_cu() > 0 ? device_num_cu() : 256;
@@ -615,19 +454,33 @@ static int launch_wino4_gemm(const float *V, const float *U, float *Mo, int NT, 
       nblocks = 8 * (int)(S < ncu / 8 ? S : ncu / 8);
     }
   }
-  // UOC_W4_PAIR (A/B): 0 = the 3-stage ring with one barrier per chunk (round 3) everywhere.  Measured per launch shape,
+#endif
+  // UOC_W4_PAIR (dev A/B): 0 = the 3-stage ring with one barrier per chunk (round 3) everywhere.  Measured per launch shape,
   // same box: layer4 383 -> 377 / 569 -> 551 / 533 -> 516 us, layer3 117.4 -> 115.8 / 165 -> 161 / 150.5 -> 147 us, layer2
   // equal, the 2-chunk items of layer1 45.0 -> 45.6 us (worse: they keep the single-chunk loop); class average 154 -> 151.5 us
-  static EnvInt pair_env("UOC_W4_PAIR", 1);
   const int cpt = Cin / W4BK;
-  const bool pair = pair_env.get() != 0 && cpt % 2 == 0 && cpt >= 4;
+  const bool pair = UOC_DEV_KNOB("UOC_W4_PAIR", 1) != 0 && cpt % 2 == 0 && cpt >= 4;
+  // waves per block: 4 (one per SIMD, wave tile BM/2 x BN/2) for the 128-wide tiles, 8 for the 64-wide ones (a 4-wave block
+  // would hold BN/2 = 32-wide wave tiles there, no better than today's); dev A/B: UOC_W4_WAVES = 8 restores round 4
+  const int nw = bn == 128 && UOC_DEV_KNOB("UOC_W4_WAVES", W4_DEFAULT_WAVES) == 4 ? 4 : 8;
 #define W4_CASE(A, B)                                                                                                \
   if (bm == A && bn == B)                                                                                            \
-    return pair ? launch_wino4_gemm_t<A, B, true>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st)                       \
-                : launch_wino4_gemm_t<A, B, false>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
+    return pair ? launch_wino4_gemm_t<A, B, true, 8>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st)                    \
+                : launch_wino4_gemm_t<A, B, false, 8>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
+#define W4_CASE4(A, B)                                                                                               \
+  if (bm == A && bn == B && nw == 4)                                                                                 \
+    return pair ? launch_wino4_gemm_t<A, B, true, 4>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st)                    \
+                : launch_wino4_gemm_t<A, B, false, 4>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
+  W4_CASE4(96, 128) W4_CASE4(128, 128) W4_CASE4(160, 128) W4_CASE4(192, 128)
+#ifdef UOC_DEV   // round-5 experiment (UOC_WINO4_TILE=160256): 256-wide block tile = wave tile 80 x 64 at 8 waves (0.1125 fragment reads per MFMA), 3-stage ring only
+  if (bn == 256 && bm == 160) return launch_wino4_gemm_t<160, 256, false, 8>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
+  if (bn == 256 && bm == 128) return launch_wino4_gemm_t<128, 256, false, 8>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
+  if (bn == 256 && bm == 96) return launch_wino4_gemm_t<96, 256, false, 8>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
+#endif
   W4_CASE(96, 128) W4_CASE(128, 128) W4_CASE(160, 128) W4_CASE(192, 128)
   W4_CASE(96, 64) W4_CASE(128, 64) W4_CASE(160, 64) W4_CASE(192, 64)
 #undef W4_CASE
+#undef W4_CASE4
   set_error("winograd F(4x4): no GEMM tile %dx%d", bm, bn);
   return UOC_EINVAL;
 }
@@ -647,7 +500,7 @@ bool wino4_eligible(const ConvParams &p) {
 
 size_t wino4_ws_floats(int G, int B, int H, int W, int d, int Cin, int Cout) {
   const Wino4Geom geo = make_geom4(B, H, W, d);
-  return (size_t)G * 36 * geo.NT * 2 * (size_t)(Cin > Cout ? Cin : Cout);   // two halves: V planes, M planes (chains of layers use them as such)
+  return (size_t)G * 36 * geo.NT * 2 * (size_t)(Cin > Cout ? Cin : Cout);   // two halves: V planes, M planes
 }
 
 int launch_wino4_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st) {
@@ -663,11 +516,7 @@ int launch_wino4_weights(const float *w, float *U, int G, int Cout, int Cin, hip
 // the blocks that are resident at once (2 per CU at ~200 VGPRs) so that all blocks walk equally long item ranges and
 // finish together instead of leaving a half-empty last round (UOC_W4_TGRID = blocks per CU, 0 = one block per 256 items).
 static long wino4_elem_blocks(long items) {
-  static int per_cu = -1;
-  if (per_cu < 0) {
-    const char *e = getenv("UOC_W4_TGRID");
-    per_cu = e ? atoi(e) : 0;
-  }
+  const int per_cu = UOC_DEV_KNOB("UOC_W4_TGRID", 0);
   long blocks = (items + 255) / 256;
   const long cap = per_cu > 0 ? (long)per_cu * (device_num_cu() > 0 ? device_num_cu() : 256) : 16384;
   return blocks < cap ? blocks : cap;
@@ -684,7 +533,7 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
   // several launches over slices of the batch (same tiles, same arithmetic: a tile never spans two images).
   const size_t per_image = (size_t)planes * make_geom4(1, p.H, p.W, p.dil).NT * (p.Cin > p.Cout ? p.Cin : p.Cout) * 4;
   UOC_REQUIRE(per_image < (1ull << 32), "winograd F(4x4): one image's frequency planes exceed 4 GB");
-  static EnvInt limit_mb("UOC_WINO4_MAX_MB", 0);   // dev / tests: a smaller limit, to exercise the split on small batches
+  static EnvInt limit_mb("UOC_SPLIT_MAX_MB", 0);   // tests: a smaller limit, to exercise the split on small batches (same results)
   const size_t limit = limit_mb.get() > 0 && ((size_t)limit_mb.get() << 20) > per_image ? (size_t)limit_mb.get() << 20 : (1ull << 32) - 1;
   const int bmax = (int)(limit / per_image);
   if (p.B > bmax) {
@@ -699,9 +548,8 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
 }
 
 // ---- the three stages of one layer, and the fused stage between two layers --------------------------------------------
-static int w4_vec() {   // channels per thread of the two elementwise kernels (UOC_W4_VEC, A/B): 4 (float4) moves the most bytes per instruction
-  static EnvInt e("UOC_W4_VEC", 4);
-  const int v = e.get();
+static int w4_vec() {   // channels per thread of the two elementwise kernels (dev A/B UOC_W4_VEC): 4 (float4) moves the most bytes per instruction
+  const int v = UOC_DEV_KNOB("UOC_W4_VEC", 4);
   return v == 1 || v == 2 ? v : 4;
 }
 
@@ -711,11 +559,13 @@ static int w4_stage_input(const ConvParams &p, const Wino4Geom &geo, float *V, h
   const int vec = w4_vec();
   ProfScope prof(KC_WINO4_INPUT, st, 0.0, 4.0 * p.G * (Mpix * p.Cin + 36.0 * geo.NT * p.Cin), tag);
   const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cin / vec));
+#ifdef UOC_DEV
   if (vec == 1)
     hipLaunchKernelGGL(wino4_input_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
   else if (vec == 2)
     hipLaunchKernelGGL(wino4_input_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
   else
+#endif
     hipLaunchKernelGGL(wino4_input_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
@@ -725,8 +575,8 @@ static int w4_stage_gemm(const ConvParams &p, const Wino4Geom &geo, const float 
   const int planes = 36 * p.G;
   const double Mpix = (double)p.B * p.H * p.W;
   const ProfTag tag = {{geo.NT, p.Cin, p.Cout, p.dil}};
-  static EnvInt gemm_env("UOC_WINO4_GEMM", 2);   // 2 = the persistent plane-GEMM kernel; 1 = one direct 1x1 "convolution" over 36*G groups (A/B, dev)
-  const int gemm_mode = gemm_env.get() == 1 ? 1 : 2;
+  // 2 = the persistent plane-GEMM kernel; 1 (dev A/B) = one direct 1x1 "convolution" over 36*G groups
+  const int gemm_mode = UOC_DEV_KNOB("UOC_WINO4_GEMM", 2) == 1 ? 1 : 2;
   // algorithmic flops = the direct 3x3 convolution's; the matrix pipe executes 36/144 of them
   // (+ the padding of partial tiles); bytes: V and U read once, M written once
   const double gflops = 2.0 * Mpix * p.Cout * p.Cin * 9.0 * p.G;
@@ -768,11 +618,13 @@ static int w4_stage_output(const ConvParams &p, const Wino4Geom &geo, const floa
   const int vec = w4_vec();
   ProfScope prof(KC_WINO4_OUTPUT, st, 0.0, 4.0 * p.G * (36.0 * geo.NT * p.Cout + Mpix * p.Cout * (p.res ? 2 : 1)), tag);
   const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cout / vec));
+#ifdef UOC_DEV
   if (vec == 1)
     hipLaunchKernelGGL(wino4_output_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
   else if (vec == 2)
     hipLaunchKernelGGL(wino4_output_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
   else
+#endif
     hipLaunchKernelGGL(wino4_output_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
@@ -791,113 +643,6 @@ static int launch_wino4_slice(const ConvParams &p0, int Bg, int b0, const float 
   if (int rc = w4_stage_input(p, geo, V, st)) return rc;
   if (int rc = w4_stage_gemm(p, geo, U, V, Mw, st)) return rc;
   return w4_stage_output(p, geo, Mw, st);
-}
-
-// ---- chains of layers (csrc/net.hip): V and M planes in caller-owned halves of the scratch; between two layers of one
-// geometry the fused kernel replaces output transform + input transform -------------------------------------------------
-// channels per block of the fused kernel: the largest slice whose LDS image (with its zero frame) fits 60 KB, so that two
-// blocks share a CU; 0 = the phase image is too large (stage-1 layer2: 62 x 82 pixels), the caller runs the two kernels
-static int w4_mid_vec() {   // channels per thread of the fused kernel: 2 (float2: 167 VGPRs, three waves per SIMD) or 4 (280 VGPRs: one wave)
-  static EnvInt e("UOC_W4_MID_VEC", 2);
-  return e.get() == 4 ? 4 : 2;
-}
-
-static int w4_mid_slice(const Wino4Geom &geo, int C) {
-  // OFF by default: measured slower end to end (profiles/r04_ab_fused_transforms.md) — the fused kernel needs ~50 KB of LDS
-  // per block and so cannot share a CU with another stream's plane GEMM, which the LDS-free separate kernels do.
-  static EnvInt on("UOC_WINO4_FUSE", 0);
-  if (on.get() == 0) return 0;
-  const int vec = w4_mid_vec(), max_threads = vec == 4 ? 256 : 512;
-  const long px = (long)(4 * geo.TH + 2) * (4 * geo.TW + 2), tiles = (long)geo.TH * geo.TW;
-  // one thread per (tile, VEC channels).  Measured (profiles/r04_ab_fused_transforms.md): the fused kernel only beats the
-  // two separate ones when a block's rows are whole 128-byte lines (>= 32 channels); the phase images of stage-1 layer3
-  // (30 x 40) and of the crops' layer2 (28 x 28) only fit LDS with 8 channels and lose.  Largest slice with at most 256
-  // items (one pass of a 4-wave block) and three blocks per CU (53 KB of LDS each); else the smallest eligible one.
-  static EnvInt min_cs("UOC_W4_MID_MIN_CS", 32);
-  int best = 0;
-  for (int cs = 8; cs <= 128; cs <<= 1) {
-    if (C % cs || px * cs * 4 > 53 * 1024) break;
-    if (cs < min_cs.get()) continue;
-    const long items = tiles * (cs / vec);
-    if (items <= 256 || (best == 0 && items <= max_threads)) best = cs;
-  }
-  return best;
-}
-
-bool wino4_chain_ok(const ConvParams &p) {   // no batch split needed (32-bit plane offsets) and eligible
-  if (!wino4_eligible(p)) return false;
-  const Wino4Geom geo = make_geom4(p.B, p.H, p.W, p.dil);
-  return (size_t)36 * p.G * geo.NT * (p.Cin > p.Cout ? p.Cin : p.Cout) * 4 < (1ull << 32) &&
-         (size_t)36 * p.G * p.Cout * p.Cin * 4 < (1ull << 32);
-}
-
-bool wino4_can_fuse(const ConvParams &prev, const ConvParams &next) {
-  return prev.G == next.G && prev.B == next.B && prev.H == next.H && prev.W == next.W && prev.dil == next.dil &&
-         prev.Cout == next.Cin && w4_mid_slice(make_geom4(prev.B, prev.H, prev.W, prev.dil), prev.Cout) > 0;
-}
-
-int wino4_chain_input(const ConvParams &p, float *V, hipStream_t st) {
-  return w4_stage_input(p, make_geom4(p.B, p.H, p.W, p.dil), V, st);
-}
-int wino4_chain_gemm(const ConvParams &p, const float *U, float *V, float *Mw, hipStream_t st) {
-  return w4_stage_gemm(p, make_geom4(p.B, p.H, p.W, p.dil), U, V, Mw, st);
-}
-int wino4_chain_output(const ConvParams &p, const float *Mw, hipStream_t st) {
-  return w4_stage_output(p, make_geom4(p.B, p.H, p.W, p.dil), Mw, st);
-}
-
-// plane GEMMs + output transform of a small-K layer in one kernel (wino4_small_kernel): V planes -> p.out
-bool wino4_small_ok(const ConvParams &p) {
-  // OFF by default: built, bit-identical, measured SLOWER (round 4, same box): 135 us against 45 + 36 us (plane GEMM +
-  // output transform) on stage-1 layer1, 137 against 40 + 20 us on layer2; 158.5 vs 166.9 frames/s.  Keeping 36 plane
-  // accumulators per lane limits a wave to a 16 x 16 tile: 512 operand bytes per MFMA from L2 (the 160 x 128 block of the
-  // plane GEMM needs 57), one plane of prefetch (0.2 us of MFMAs) cannot cover the L2 latency, and the register budget
-  // allows neither a larger tile nor a deeper prefetch.
-  static EnvInt on("UOC_WINO4_SMALL", 0);
-  return on.get() != 0 && p.Cin == p.Cout && (p.Cin == 64 || p.Cin == 128);
-}
-
-int wino4_chain_gemm_out(const ConvParams &p, const float *U, const float *V, hipStream_t st) {
-  const Wino4Geom geo = make_geom4(p.B, p.H, p.W, p.dil);
-  const int grid = p.G * ((geo.NT + 15) / 16);
-  const double Mpix = (double)p.B * p.H * p.W;
-  const ProfTag tag = {{geo.NT, p.Cin, p.Cout, p.dil}};
-  ProfScope prof(KC_WINO4_SMALL, st, 2.0 * Mpix * p.Cout * p.Cin * 9.0 * p.G,
-                 4.0 * p.G * (36.0 * geo.NT * p.Cin + 36.0 * p.Cout * p.Cin + Mpix * p.Cout * (p.res ? 2 : 1)), tag);
-  if (p.Cin == 64)
-    hipLaunchKernelGGL(wino4_small_kernel<64>, dim3(grid), dim3(256), 0, st, V, U, p.bias, p.res, p.out, geo, p.G, p.relu);
-  else
-    hipLaunchKernelGGL(wino4_small_kernel<128>, dim3(grid), dim3(512), 0, st, V, U, p.bias, p.res, p.out, geo, p.G, p.relu);
-  UOC_LAUNCH_CHECK();
-  return UOC_OK;
-}
-
-// prev's output transform (bias, residual, ReLU; its NHWC tensor prev.out is written only if write_y) + the next layer's
-// input transform: Mw (prev's M planes) -> V (the next layer's V planes)
-int wino4_chain_mid(const ConvParams &prev, bool write_y, const float *Mw, float *V, hipStream_t st) {
-  const Wino4Geom geo = make_geom4(prev.B, prev.H, prev.W, prev.dil);
-  const int C = prev.Cout, cs = w4_mid_slice(geo, C);
-  UOC_REQUIRE(cs > 0, "winograd F(4x4): layers cannot be fused");
-  const int sib = cs < 32 ? 32 / cs : 1;
-  const int units = prev.G * prev.B * prev.dil * prev.dil * (C / cs);
-  const int grid = (units + 8 * sib - 1) / (8 * sib) * (8 * sib);
-  const int vec = w4_mid_vec();
-  const int items = geo.TH * geo.TW * (cs / vec);
-  int threads = (items + 63) / 64 * 64;
-  if (threads > (vec == 4 ? 256 : 512)) threads = vec == 4 ? 256 : 512;
-  const size_t lds = (size_t)(4 * geo.TH + 2) * (4 * geo.TW + 2) * cs * 4;
-  const double Mpix = (double)prev.B * prev.H * prev.W;
-  const ProfTag tag = {{geo.NT, C, C, prev.dil}};
-  ProfScope prof(KC_WINO4_MID, st, 0.0,
-                 4.0 * prev.G * (2.0 * 36.0 * geo.NT * C + Mpix * C * ((prev.res ? 1 : 0) + (write_y ? 1 : 0))), tag);
-  if (vec == 4)
-    hipLaunchKernelGGL(wino4_mid_kernel<4>, dim3((unsigned)grid), dim3(threads), lds, st, Mw, prev.bias, prev.res,
-                       write_y ? prev.out : nullptr, V, geo, prev.G, C, prev.relu, cs, sib, units);
-  else
-    hipLaunchKernelGGL(wino4_mid_kernel<2>, dim3((unsigned)grid), dim3(threads), lds, st, Mw, prev.bias, prev.res,
-                       write_y ? prev.out : nullptr, V, geo, prev.G, C, prev.relu, cs, sib, units);
-  UOC_LAUNCH_CHECK();
-  return UOC_OK;
 }
 
 }  // namespace uoc

@@ -27,6 +27,15 @@ def shard_range(num_frames: int, rank: int, world: int):
     return lo, min(lo + per, num_frames)
 
 
+def config_fingerprint() -> int:
+    """63 bits of uoc_config_fingerprint() (what could make two ranks compute different bits); $UOC_TEST_FINGERPRINT
+    overrides it in the CPU tests of the mismatch path."""
+    if os.environ.get("UOC_TEST_FINGERPRINT"):
+        return int(os.environ["UOC_TEST_FINGERPRINT"])
+    from . import _native
+    return _native.config_fingerprint() & 0x7FFFFFFFFFFFFFFF
+
+
 def frame_rng_seed(frame_index: int) -> int:
     return int(cfg.RNG_SEED) + int(frame_index)
 
@@ -51,10 +60,11 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     rank of a larger job does for its block, without emulating a rank / world pair (tests that walk a long frame list in
     resident chunks).
 
-    `timing`: if given, receives this rank's 'compute_s' (its frame block, device-synchronised) and 'gather_s' (error-flag
+    `timing`: if given, receives this rank's 'compute_s' (its frame block, device-synchronised), 'host_cpu_s' (CPU seconds
+    the process spent on it: the event-driven host loop polls, so about one core per rank) and 'gather_s' (error-flag
     all-reduce + all_gather) — the per-rank breakdown bench.py prints for multi-GPU runs."""
     import time
-    t_start = time.perf_counter()
+    t_start, t_cpu = time.perf_counter(), time.process_time()
     per = (num_frames + world - 1) // world
     lo, hi = shard_range(num_frames, rank, world) if block_range is None else block_range
     if block_range is not None:
@@ -87,6 +97,7 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
         if device.type == "cuda":
             torch.cuda.synchronize(device)
         timing["compute_s"] = time.perf_counter() - t_start
+        timing["host_cpu_s"] = time.process_time() - t_cpu     # CPU seconds of this process (all threads) over its block: the rank's core budget
         timing["frames"] = hi - lo
     if not collective:
         return block[:hi - lo]
@@ -95,12 +106,20 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     # on one GPU; on the GPU node the backend is nccl = RCCL and everything stays on the device)
     staged = device.type == "cuda" and dist.get_backend() == "gloo"
     coll_dev = torch.device("cpu") if staged else device
-    flag = torch.tensor([1 if error is not None else 0], dtype=torch.int32, device=coll_dev)
+    # one MAX all-reduce carries the error flag AND the configuration fingerprint (library version / development build and
+    # its rounding-affecting knobs) as (fp, -fp): max(fp) != -max(-fp) means two ranks would not compute the same bits for
+    # the same frame — sharding independence broken silently — so every rank fails before the gather
+    fp = config_fingerprint()
+    flag = torch.tensor([1 if error is not None else 0, fp, -fp], dtype=torch.int64, device=coll_dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-    if int(flag.item()) != 0:
+    flag = flag.tolist()
+    if flag[0] != 0:
         if error is not None:
             raise error
         raise RuntimeError("another rank failed in its frame block; aborting before the all_gather")
+    if flag[1] != -flag[2]:
+        raise RuntimeError("ranks run different libuoc_hip configurations (uoc_config_fingerprint differs: library version, "
+                           f"development build or a rounding-affecting knob); this rank: {fp}")
     full = torch.empty((world * per, height, width), dtype=torch.uint8, device=coll_dev)
     dist.all_gather_into_tensor(full, block.to(coll_dev))
     full = full.to(device)
