@@ -22,7 +22,8 @@ IMPLICIT_M0 = re.compile(r"^\s*(s_movrel|v_movrel|s_sendmsg|ds_gws|ds_\w*addtid|
 def _asm(tmp, name):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = os.path.join(tmp, name + ".s")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", os.path.join(CSRC, name),
+    # -DUOC_DEV: the superset (the shipped kernels are the same code; the development build adds wino.hip and the alternates)
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DUOC_DEV", "-S", "--cuda-device-only", os.path.join(CSRC, name),
                     "-o", out], check=True, stderr=subprocess.DEVNULL)
     return open(out).read()
 
