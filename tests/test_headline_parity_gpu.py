@@ -236,6 +236,28 @@ def _decompose(g, fix, sd, net, net_crop, device, end_to_end=True, live_oracle_f
     return row
 
 
+def _decompose_many(frames, fix, sd, net, net_crop, device, end_to_end, live_oracle_fallback):
+    """_decompose over a list of frames with the oracle's network passes (the cost: two CPU backbone passes per frame)
+    computed a few frames ahead in worker processes and handed over through files."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ProcessPoolExecutor
+    import multiprocessing as mp
+    tmp = tempfile.mkdtemp(prefix="uoc_parity_")       # (a container's /dev/shm may hold 64 MB; the page cache does the same job)
+    ncpu = len(os.sched_getaffinity(0))
+    nwork = max(1, min(8, ncpu // 16))
+    out = []
+    try:
+        with ProcessPoolExecutor(nwork, mp_context=mp.get_context("spawn")) as pool:     # spawn: this process holds a HIP context
+            for lo in range(0, len(frames), 2 * nwork):       # bounded run-ahead: ~170 MB of embeddings per frame
+                for g in pool.map(_oracle_embed_worker, [(g, tmp, max(4, min(16, ncpu // nwork))) for g in frames[lo:lo + 2 * nwork]]):
+                    out.append(_decompose(g, fix, sd, net, net_crop, device, end_to_end=end_to_end,
+                                          live_oracle_fallback=live_oracle_fallback, shm=tmp))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def test_embeddings_and_integer_path_separately(device, nets):
     """(a) + (b) on bench frames 0 .. DECOMPOSED_FRAMES-1."""
     sd, net, net_crop = nets
@@ -244,7 +266,8 @@ def test_embeddings_and_integer_path_separately(device, nets):
     if os.environ.get("UOC_PARITY_FRAME_LIST"):        # ad hoc: the decomposition on chosen frames, e.g. the histogram's outliers
         frames = [int(v) for v in os.environ["UOC_PARITY_FRAME_LIST"].split(",")]
     assert len(frames) >= min(DECOMPOSED_FRAMES, 8) or os.environ.get("UOC_PARITY_FRAME_LIST"), "tests/golden/bench_oracle/ is missing"
-    report = [_decompose(g, fix, sd, net, net_crop, device, live_oracle_fallback=bool(os.environ.get("UOC_PARITY_FRAME_LIST"))) for g in frames]
+    report = _decompose_many(frames, fix, sd, net, net_crop, device, end_to_end=True,
+                             live_oracle_fallback=bool(os.environ.get("UOC_PARITY_FRAME_LIST")))
     worst_embed = max(max(r["embed_err_stage1"], r["embed_err_crops"]) for r in report)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     summary = {"frames": len(frames), "embed_max_err": worst_embed,
@@ -347,15 +370,9 @@ def test_end_to_end_margin_bounded(device, nets):
     import shutil
     import tempfile
     t_start = time.time()
-    shm = tempfile.mkdtemp(prefix="uoc_parity_")       # (a container's /dev/shm may hold 64 MB; the page cache does the same job)
-    ncpu = len(os.sched_getaffinity(0))
-    nwork = max(1, min(8, ncpu // 16))
-    decomposed = []
-    with ProcessPoolExecutor(nwork, mp_context=mp.get_context("spawn")) as epool:     # the oracle's backbone passes, a few frames ahead
-        for lo in range(0, len(mismatching), 2 * nwork):       # bounded run-ahead: ~170 MB of embeddings per frame
-            for g in epool.map(_oracle_embed_worker, [(g, shm, max(4, min(16, ncpu // nwork))) for g in mismatching[lo:lo + 2 * nwork]]):
-                decomposed.append(_decompose(g, fix, sd, net, net_crop, device, end_to_end=False, live_oracle_fallback=True, shm=shm))
+    decomposed = _decompose_many(mismatching, fix, sd, net, net_crop, device, end_to_end=False, live_oracle_fallback=True)
     t_dec = time.time() - t_start
+    shm = tempfile.mkdtemp(prefix="uoc_parity_")
     def _rounding_only(r):
         px = r["given_oracle_embeddings"].get("kernel_rounding_pixels")
         return bool(px) and len(px) <= MAX_KERNEL_ROUNDING_PIXELS and all(p["margin"] <= M.TAU for p in px)
