@@ -29,6 +29,15 @@ def test_block_is_independent_of_frames_in_flight(device):
         blocks[depth, group] = runner.run_sharded(5, fn, 480, 640, device, 0, 1, False, inflight=depth).cpu()
         torch.cuda.synchronize()
         counts[depth, group] = list(fn.roi_counts)
+    # (3, 4) and (2, 3) above ran with the balanced tail (5 frames: (2, 2, 1) and (3, 2)); the same with full sets ((4, 1), (3, 2))
+    import os
+    os.environ["UOC_PIPE_TAIL"] = "0"
+    try:
+        fn = runner.two_stage_frame_fn(samples, net, net_crop, frames_per_launch=4)
+        blocks[3, 40] = runner.run_sharded(5, fn, 480, 640, device, 0, 1, False, inflight=3).cpu()
+        counts[3, 40] = list(fn.roi_counts)
+    finally:
+        os.environ.pop("UOC_PIPE_TAIL", None)
     ref = blocks[1, 1]
     assert ref.shape == (5, 480, 640) and int(ref.max()) >= 5
     for key, b in blocks.items():

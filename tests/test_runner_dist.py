@@ -83,3 +83,18 @@ def test_ranks_with_different_library_configurations_fail_before_the_gather(tmp_
 def test_the_fingerprint_is_the_library_s():
     from unseenobjectclustering_amd import _native
     assert runner.config_fingerprint() == _native.config_fingerprint() & 0x7FFFFFFFFFFFFFFF > 0
+
+
+def test_launch_set_plan():
+    """The launch sets of a frame block: full sets, and a partial last round spread over all streams (speed only)."""
+    f = runner.launch_set_sizes
+    assert f(20, 4, 3) == [4, 4, 4, 3, 3, 2] and f(20, 4, 3, False) == [4, 4, 4, 4, 4]
+    assert f(64, 4, 3) == [4] * 16                      # remainder = one set: untouched
+    assert f(8, 4, 3) == [3, 3, 2] and f(5, 4, 3) == [2, 2, 1] and f(3, 4, 3) == [3] and f(12, 4, 3) == [4, 4, 4]
+    assert f(7, 4, 1) == [4, 3] and f(0, 4, 3) == []
+    for n in range(0, 70):
+        for group in (1, 2, 4, 6):
+            for depth in (1, 2, 3, 4):
+                for tail in (False, True):
+                    s = f(n, group, depth, tail)
+                    assert sum(s) == n and all(1 <= v <= group for v in s)

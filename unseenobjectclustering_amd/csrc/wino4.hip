@@ -547,7 +547,7 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
   return launch_wino4_slice(p, p.B, 0, U, ws, st);
 }
 
-// ---- the three stages of one layer, and the fused stage between two layers --------------------------------------------
+// ---- the three stages of one layer ---------------------------------------------------------------------------------
 static int w4_vec() {   // channels per thread of the two elementwise kernels (dev A/B UOC_W4_VEC): 4 (float4) moves the most bytes per instruction
   const int v = UOC_DEV_KNOB("UOC_W4_VEC", 4);
   return v == 1 || v == 2 ? v : 4;
