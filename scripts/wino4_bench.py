@@ -35,8 +35,9 @@ def measure(B, H, W, C, dil, algo, env, iters=10):
     w = torch.randn(G, 9, C, C, device=dev, generator=gen) * 0.02
     b = torch.randn(G, C, device=dev, generator=gen)
     out = torch.empty(G, B, H, W, C, device=dev)
+    res = torch.randn(G, B, H, W, C, device=dev, generator=gen) if os.environ.get("WINO4_BENCH_RESIDUAL", "1") != "0" else None   # conv2 of a BasicBlock
     st = _native.stream_ptr(dev)
-    run = lambda: _native.check(L.uoc_conv2d_nhwc_algo(P(x), P(w), P(b), None, P(out), G, B, H, W, C, C, 3, 1, dil, dil, 1, algo, st), "conv")
+    run = lambda: _native.check(L.uoc_conv2d_nhwc_algo(P(x), P(w), P(b), P(res), P(out), G, B, H, W, C, C, 3, 1, dil, dil, 1, algo, st), "conv")
     for _ in range(3):
         run()
     torch.cuda.synchronize()

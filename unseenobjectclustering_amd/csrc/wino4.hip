@@ -26,6 +26,9 @@
 namespace uoc {
 
 constexpr int W4BK = 32;  // cin chunk (floats): one 128-byte row piece per DMA lane group
+#ifndef W4_OUT_MIN_BLOCKS
+#define W4_OUT_MIN_BLOCKS 2   // blocks per CU the output transform is compiled for: two waves per SIMD = at most 256 registers per lane (8 of them spill)
+#endif
 #ifndef W4_DEFAULT_WAVES
 #define W4_DEFAULT_WAVES 8   // waves per plane-GEMM block on the 128-wide tiles (see wino4_gemm_kernel)
 #endif
@@ -56,7 +59,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restric
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restrict__ M, const float *__restrict__ bias,
+__global__ __launch_bounds__(256, W4_OUT_MIN_BLOCKS) void wino4_output_kernel(const float *__restrict__ M, const float *__restrict__ bias,
                                                            const float *__restrict__ res, float *__restrict__ out,
                                                            Wino4Geom geo, int G, int Cout, int relu) {
   const int CV = Cout / VEC;

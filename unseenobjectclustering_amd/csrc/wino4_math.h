@@ -232,15 +232,6 @@ __host__ __device__ inline void wino4_output_tile(const T (&m)[36], T (&y)[4][4]
   for (int a = 0; a < 4; ++a) wino4_at(s[a], y[a]);
 }
 
-// the epilogue every output path shares: + bias (+ residual), ReLU
-template <typename T>
-__host__ __device__ inline T wino4_epilogue(T y, T bv, const float *res_at, int relu) {
-  T v = w4_add(y, bv);
-  if (res_at) v = w4_add(v, *reinterpret_cast<const T *>(res_at));
-  if (relu) v = w4_relu(v);
-  return v;
-}
-
 // out[g][b][y][x][cout] = relu?(A^T M A + bias (+ res)) for channels VEC*cv .. of tile tau; M: [(g*36 + xi)][tile][cout]
 template <int VEC>
 __host__ __device__ inline void wino4_output_body(const float *M, const float *bias, const float *res, float *out,
@@ -251,11 +242,45 @@ __host__ __device__ inline void wino4_output_body(const float *M, const float *b
   T m[36];
 #pragma unroll
   for (int k = 0; k < 36; ++k) m[k] = W4_STREAM_LOAD(T, src + (size_t)k * plane);
-  T yv[4][4];
-  wino4_output_tile(m, yv);
   int b, oy, ox;
   wino4_decode(tau, geo, b, oy, ox);
   const size_t gsz = (size_t)geo.Bg * geo.H * geo.W * Cout;
+  const size_t o0 = (size_t)g * gsz + (((size_t)b * geo.H + oy) * geo.W + ox) * Cout + VEC * cv;
+  const size_t oy_step = (size_t)geo.d * geo.W * Cout, ox_step = (size_t)geo.d * Cout;
+  // The 16 residual values are loaded UP FRONT, next to the 36 frequencies (round 5).  Loaded where they are used — one load,
+  // one wait, one store, sixteen times in a row, because the compiler may not move a load of `res` across a store to `out` — the
+  // kernel paid sixteen dependent memory round trips per thread: 4.0-4.7 TB/s on the residual layers against 5.5 without.
+#ifndef W4_OUT_RES_MODE
+#define W4_OUT_RES_MODE 2   // 2 = residual loads after the column pass (fewest live registers; measured best), 1 = up front, 0 = at the stores (round 4)
+#endif
+  T rv[4][4];
+#define W4_LOAD_RES()                                                                        \
+  if (res) {                                                                                 \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int e = 0; e < 4; ++e) { \
+      if (oy + a * geo.d < geo.H && ox + e * geo.d < geo.W)                                  \
+        rv[a][e] = *reinterpret_cast<const T *>(res + o0 + a * oy_step + e * ox_step);       \
+      else                                                                                   \
+        w4_zero(rv[a][e]);                                                                   \
+    }                                                                                        \
+  }
+  if (W4_OUT_RES_MODE == 1) { W4_LOAD_RES() }
+  T yv[4][4];
+  {
+    T s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      T col[6], o[4];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) col[i] = m[6 * i + j];
+      wino4_at(col, o);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) s[a][j] = o[a];
+    }
+    if (W4_OUT_RES_MODE == 2) { W4_LOAD_RES() }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) wino4_at(s[a], yv[a]);
+  }
+#undef W4_LOAD_RES
   T bv;
   if (bias)
     bv = *reinterpret_cast<const T *>(bias + (size_t)g * Cout + VEC * cv);
@@ -269,8 +294,10 @@ __host__ __device__ inline void wino4_output_body(const float *M, const float *b
     for (int e = 0; e < 4; ++e) {
       const int x = ox + e * geo.d;
       if (x >= geo.W) continue;
-      const size_t o = (size_t)g * gsz + (((size_t)b * geo.H + y) * geo.W + x) * Cout + VEC * cv;
-      *reinterpret_cast<T *>(out + o) = wino4_epilogue(yv[a][e], bv, res ? res + o : nullptr, relu);
+      T v = w4_add(yv[a][e], bv);                 // + bias, + residual, ReLU — in this order
+      if (res) v = w4_add(v, W4_OUT_RES_MODE == 0 ? *reinterpret_cast<const T *>(res + o0 + a * oy_step + e * ox_step) : rv[a][e]);
+      if (relu) v = w4_relu(v);
+      *reinterpret_cast<T *>(out + o0 + a * oy_step + e * ox_step) = v;
     }
   }
 }
