@@ -234,7 +234,13 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
   float4 *lds = reinterpret_cast<float4 *>(smem) + tid;  // chunk c4 at lds[c4 * FPP_THREADS]
 
   // ---- load this thread's pixels once -------------------------------------------------------
-  float x[FPP_RS][C];
+  // Register pixels 0 and 1 are kept as PAIRS (round 5): their two dot products run as v_pk_fma_f32 — two fused multiply-adds per
+  // lane and instruction, each pixel's sum still one sequential fma chain over the channels (bit-identical to the scalar form),
+  // the seed row's scalars broadcast through op_sel.  The step's 256 dependent-chain FMAs per lane were 0.9 of its ~5.5 us.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  static_assert(FPP_RS == 3, "pixels 0/1 packed, pixel 2 scalar");
+  f32x2 x01[C];
+  float x2[C];
 #pragma unroll
   for (int j = 0; j < FPP_RS; ++j) {
     const int p = pbase + j * FPP_THREADS;
@@ -242,10 +248,13 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
 #pragma unroll
     for (int c4 = 0; c4 < C / 4; ++c4) {
       const float4 v = ok ? *reinterpret_cast<const float4 *>(X + (size_t)p * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      x[j][4 * c4 + 0] = v.x;
-      x[j][4 * c4 + 1] = v.y;
-      x[j][4 * c4 + 2] = v.z;
-      x[j][4 * c4 + 3] = v.w;
+      const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (j == 0) x01[4 * c4 + k].x = e[k];
+        if (j == 1) x01[4 * c4 + k].y = e[k];
+        if (j == 2) x2[4 * c4 + k] = e[k];
+      }
     }
   }
   if (nslots > FPP_RS) {
@@ -276,12 +285,18 @@ __global__ __launch_bounds__(FPP_THREADS) void fps_persistent_kernel(
     // the seed row: `cur` is wave-uniform, so these are scalar loads and the FMAs take SGPR operands
     const float *__restrict__ srow = X + (size_t)cur * C;
     ArgMax best = {-INFINITY, INT_MAX};
+    f32x2 s01 = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < C; ++c) s01 = __builtin_elementwise_fma(x01[c], f32x2{srow[c], srow[c]}, s01);
+    float s2 = 0.f;
+    if (nslots > 2) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) s2 = fmaf(x2[c], srow[c], s2);
+    }
 #pragma unroll
     for (int j = 0; j < FPP_RS; ++j) {
       if (j < nslots) {
-        float s_ = 0.f;
-#pragma unroll
-        for (int c = 0; c < C; ++c) s_ = fmaf(x[j][c], srow[c], s_);
+        const float s_ = j == 0 ? s01.x : j == 1 ? s01.y : s2;
         float d_ = 0.5f * (1.0f - s_);
         if (step > 0) d_ = fminf(d_, dm[j]);
         dm[j] = d_;
