@@ -50,7 +50,14 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restric
                                                           Wino4Geom geo, int G, int C) {
   const int CV = C / VEC;
   const long total = (long)G * geo.NT * CV;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+#ifndef W4_IN_XCD
+#define W4_IN_XCD 1
+#endif
+  // XCD-aware block order (the grid is a multiple of 8): hardware block b runs on XCD b % 8; virtual block = (b % 8) * (grid / 8)
+  // + b / 8 gives every XCD one CONTIGUOUS eighth of the tiles, so the 6x6 patches of neighbouring tiles — which share two of
+  // their six rows / columns — are fetched into ONE L2 instead of eight
+  const long vblock = W4_IN_XCD ? (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (long)blockIdx.x;
+  for (long idx = vblock * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int cv = (int)(idx % CV);
     const int tau = (int)((idx / CV) % geo.NT);
     const int g = (int)(idx / ((long)CV * geo.NT));
@@ -522,7 +529,8 @@ static long wino4_elem_blocks(long items) {
   const int per_cu = UOC_DEV_KNOB("UOC_W4_TGRID", 0);
   long blocks = (items + 255) / 256;
   const long cap = per_cu > 0 ? (long)per_cu * (device_num_cu() > 0 ? device_num_cu() : 256) : 16384;
-  return blocks < cap ? blocks : cap;
+  blocks = blocks < cap ? blocks : cap;
+  return (blocks + 7) / 8 * 8;     // a multiple of 8: the input transform deals its blocks to the XCDs in contiguous eighths
 }
 
 static int launch_wino4_slice(const ConvParams &p0, int Bg, int b0, const float *U, float *ws, hipStream_t st);
