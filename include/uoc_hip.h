@@ -35,11 +35,10 @@ extern "C" {
 #define UOC_MAX_SEEDS 128  /* num_seeds upper bound (reference default 100)   */
 
 int uoc_version(void);
-/* 1 for a development build (-DUOC_DEV: alternate kernels and their UOC_* knobs compiled in), 0 for the shipped library,
- * in which every kernel choice that affects rounding is a compile-time constant. */
+/* Always 0 since round 6: every kernel choice that affects rounding is a compile-time constant and the library holds one
+ * implementation per step (rounds 3-5 had a -DUOC_DEV build with the measured-and-rejected alternates).  Kept for ABI stability. */
 int uoc_is_dev_build(void);
-/* Hash of everything that could make two processes compute different bits (library version, development build and, there,
- * the rounding-affecting knobs).  The frame-parallel runner all-reduces it next to its error flag: ranks that disagree
+/* Hash of everything that could make two processes compute different bits (the library version).  The frame-parallel runner all-reduces it next to its error flag: ranks that disagree
  * fail before the gather instead of silently breaking sharding independence. */
 unsigned long long uoc_config_fingerprint(void);
 /* Releases process-wide helper objects (the per-device events that order the persistent sampling kernels of
@@ -157,11 +156,9 @@ int uoc_net_forward(uoc_net *net, const float *d_rgb, const float *d_xyz, int B,
  * Cin % 32 == 0, Cout % 64 == 0.  Exposed for unit tests / micro-benchmarks of the conv kernels.
  * uoc_conv2d_nhwc runs the direct implicit-GEMM kernel.  uoc_conv2d_nhwc_algo names the algorithm explicitly (no
  * environment variable decides it): UOC_CONV_DIRECT, or UOC_CONV_WINOGRAD4 = F(4x4,3x3) as the network runs its 3x3
- * stride-1 layers from 64 channels up (UOC_EINVAL if the shape is not eligible).  Development builds also accept
- * UOC_CONV_WINOGRAD2 (the F(2x2,3x3) kernels of rounds 1-2).  The Winograd path keeps its transformed weights and
+ * stride-1 layers from 64 channels up (UOC_EINVAL if the shape is not eligible).  The Winograd path keeps its transformed weights and
  * scratch in buffers owned by this entry: one caller thread at a time. */
 #define UOC_CONV_DIRECT 0
-#define UOC_CONV_WINOGRAD2 2
 #define UOC_CONV_WINOGRAD4 4
 int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, const float *d_res, float *d_out,
                     int G, int B, int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu,

@@ -1,9 +1,8 @@
-"""Dev helper (DEVELOPMENT build: python -m unseenobjectclustering_amd.build --dev; run with
-UOC_LIB_PATH=unseenobjectclustering_amd/libuoc_hip_dev.so): one 3x3 layer as Winograd F(4x4,3x3) (csrc/wino4.hip) on the
-launch shapes of the pipeline (four frames per launch set in stage 1, ~28 crops in stage 2) under the plane GEMM's knobs
-(waves per block, tile overrides, planes as groups of the direct 1x1 kernel), next to F(2x2,3x3) and the direct kernel.
-Times from the library's per-kernel-class HIP events; TF = algorithmic (direct 3x3) flops over the summed time of the
-layer's kernels.  WINO4_BENCH_ONLY=<substring> restricts the arms, WINO4_BENCH_SHAPES=<substring> the shapes."""
+"""Micro-benchmark: one 3x3 layer as Winograd F(4x4,3x3) (csrc/wino4.hip) on the launch shapes of the pipeline (four frames
+per launch set in stage 1, ~28 crops in stage 2, one frame alone) next to the direct kernel.  Times from the library's
+per-kernel-class HIP events; TF = algorithmic (direct 3x3) flops over the summed time of the layer's kernels.
+WINO4_BENCH_SHAPES=<substring> restricts the shapes.  (The A/B arms of rounds 3-5 — waves per block, tile overrides, planes
+as groups, F(2x2) — needed the development build that round 6 removed; their results are in HISTORY.md.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,7 +11,7 @@ dev = torch.device("cuda:0")
 L = _native.lib()
 P = _native.ptr
 G = 2
-KNOBS = ("UOC_WINO4_GEMM", "UOC_WINO4_TILE", "UOC_W4_WAVES", "UOC_W4_PAIR")
+KNOBS = ()
 shapes = [  # name, B, H, W, C, dil
     ("s1 layer4 512 d4 4x60x80", 4, 60, 80, 512, 4),
     ("s1 layer3 256 d2 4x60x80", 4, 60, 80, 256, 2),
@@ -50,15 +49,7 @@ def measure(B, H, W, C, dil, algo, env, iters=10):
     return rep, out
 
 
-is_dev = L.uoc_is_dev_build() == 1
-arms = [("F4 8 waves auto", 4, {"UOC_W4_WAVES": "8"}), ("F4 4 waves auto", 4, {"UOC_W4_WAVES": "4"})]
-if is_dev:
-    arms += [(f"F4 {nw} waves {t // 1000}x{t % 1000}", 4, {"UOC_W4_WAVES": str(nw), "UOC_WINO4_TILE": str(t)})
-             for t in (192128, 160128, 128128, 96128) for nw in (8, 4)]
-    arms += [(f"F4 8 waves {t // 1000}x{t % 1000} wide", 4, {"UOC_W4_WAVES": "8", "UOC_WINO4_TILE": str(t)}) for t in (160256, 128256, 96256)]
-    arms += [("F4 planes-as-groups", 4, {"UOC_WINO4_GEMM": "1"}), ("F2", 2, {})]
-else:
-    arms = [("F4 shipped", 4, {})]
+arms = [("F4 shipped", 4, {})]
 arms.append(("direct", 0, {}))
 for name, B, H, W, C, dil in shapes:
     if os.environ.get("WINO4_BENCH_SHAPES") and os.environ["WINO4_BENCH_SHAPES"] not in name:

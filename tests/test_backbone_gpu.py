@@ -145,22 +145,11 @@ WINO4_EXTRA_CASES = [
 ]
 
 
-def _algos():
-    """The shipped library holds ONE Winograd path (F(4x4,3x3), persistent plane GEMM).  A development build
-    (python -m unseenobjectclustering_amd.build --dev, loaded through UOC_LIB_PATH) also carries the measured alternates."""
-    dev = _native.lib().uoc_is_dev_build() == 1
-    return ["f4", "f2", "f4-planes-as-groups"] if dev else ["f4"]
-
-
-@pytest.mark.parametrize("algo", _algos())
 @pytest.mark.parametrize("case", WINO_CASES + WINO4_EXTRA_CASES)
-def test_winograd_conv_vs_torch_cpu(device, case, algo):
+def test_winograd_conv_vs_torch_cpu(device, case):
     """Winograd F(4x4,3x3) (csrc/wino4.hip) against torch CPU conv2d; fp32 Winograd differs from the direct sum only by
-    rounding (bar: 2e-4 of the output scale, measured ~1e-6).  Development builds: also the planes as groups of the direct
-    1x1 kernel and F(2x2,3x3) (csrc/wino.hip)."""
+    rounding (bar: 2e-4 of the output scale, measured ~1e-6)."""
     G, B, H, W, Cin, Cout, dil, use_res, relu = case
-    if algo == "f2" and case in WINO4_EXTRA_CASES[:2]:
-        pytest.skip("large cases are for the F(4x4) item loop")
     g = torch.Generator().manual_seed(abs(hash(case)) % (2 ** 31))
     x = torch.randn(G, B, Cin, H, W, generator=g)
     w = torch.randn(G, Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
@@ -171,8 +160,7 @@ def test_winograd_conv_vs_torch_cpu(device, case, algo):
         ref = ref + res
     if relu:
         ref = F.relu(ref)
-    env = {"UOC_WINO4_GEMM": "1"} if algo == "f4-planes-as-groups" else None
-    got = _wino4_conv(device, x, w, b, res, dil, relu, env=env, algo=_native.CONV_WINOGRAD2 if algo == "f2" else _native.CONV_WINOGRAD4)
+    got = _wino4_conv(device, x, w, b, res, dil, relu)
     err = (got - ref).abs().max().item()
     assert err < 2e-4 * max(1.0, ref.abs().max().item()), err
 

@@ -1,4 +1,4 @@
-"""The LDS-DMA helpers (csrc/dma.h, wglds16s in csrc/wino.hip) write M0 from inline asm without saving, restoring or
+"""The LDS-DMA helpers (csrc/dma.h) write M0 from inline asm without saving, restoring or
 declaring it (two scalar moves per DMA less).  That is safe only while the compiler never keeps a value of its own in
 M0 across those statements.  This test disassembles the kernels that use them and checks, per kernel:
   * every instruction that mentions m0 is one of the helpers' own `s_mov_b32 m0, <lds address>`;
@@ -15,15 +15,14 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "unseenobjectclustering_amd", "csrc")
-FILES = ("conv.hip", "wino.hip", "wino4.hip")
+FILES = ("conv.hip", "wino4.hip")
 IMPLICIT_M0 = re.compile(r"^\s*(s_movrel|v_movrel|s_sendmsg|ds_gws|ds_\w*addtid|v_interp|ds_\w+_gs\b)")
 
 
 def _asm(tmp, name):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     out = os.path.join(tmp, name + ".s")
-    # -DUOC_DEV: the superset (the shipped kernels are the same code; the development build adds wino.hip and the alternates)
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DUOC_DEV", "-S", "--cuda-device-only", os.path.join(CSRC, name),
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", os.path.join(CSRC, name),
                     "-o", out], check=True, stderr=subprocess.DEVNULL)
     return open(out).read()
 

@@ -71,8 +71,8 @@ def test_argument_validation_without_gpu():
 
 
 def test_shipped_library_has_no_result_affecting_knobs():
-    """The shipped library is not a development build, reads only the speed-only variables INTEGRATION.md lists, and its
-    configuration fingerprint does not move with the rounding-affecting knobs of development builds."""
+    """The library reads only the speed-only variables INTEGRATION.md lists, and its configuration fingerprint does not move with
+    the rounding-affecting knobs the development builds of rounds 3-5 had (there is no development build any more)."""
     lib = _native.lib()
     assert lib.uoc_is_dev_build() == 0
     blob = open(LIB_PATH, "rb").read()

@@ -130,7 +130,7 @@ def lib():
     return _lib
 
 
-CONV_DIRECT, CONV_WINOGRAD2, CONV_WINOGRAD4 = 0, 2, 4       # include/uoc_hip.h: UOC_CONV_*
+CONV_DIRECT, CONV_WINOGRAD4 = 0, 4       # include/uoc_hip.h: UOC_CONV_*
 
 
 def config_fingerprint() -> int:

@@ -12,8 +12,7 @@ import subprocess
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_PATH = os.environ.get("UOC_LIB_PATH") or os.path.join(PKG_DIR, "libuoc_hip.so")   # override: load a development build
-DEV_LIB_PATH = os.path.join(PKG_DIR, "libuoc_hip_dev.so")
+LIB_PATH = os.environ.get("UOC_LIB_PATH") or os.path.join(PKG_DIR, "libuoc_hip.so")   # override: load another build (A/B measurements)
 ARCH = "gfx950"
 
 
@@ -30,15 +29,8 @@ def _stale() -> bool:
     return any(os.path.getmtime(p) > t for p in deps)
 
 
-def build_native(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
-    """Compile every csrc/*.hip into libuoc_hip.so.  Returns the library path.
-
-    dev=True (python -m unseenobjectclustering_amd.build --dev): the same sources with -DUOC_DEV into libuoc_hip_dev.so —
-    the measured-and-rejected alternates (Winograd F(2x2), the register-staged direct kernel, timing ablations) and the
-    UOC_* development knobs that select them.  Load it with UOC_LIB_PATH=<that file> (scripts/ab.sh does); the shipped
-    library contains none of it."""
-    if dev:
-        return _build(DEV_LIB_PATH, "build_dev", ["-DUOC_DEV"], True, verbose)
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    """Compile every csrc/*.hip into libuoc_hip.so.  Returns the library path."""
     if not force and not _stale():
         return LIB_PATH
     return _build(LIB_PATH, "build", [], force, verbose)
@@ -75,4 +67,4 @@ def _build(lib_path: str, objdir: str, flags, force: bool, verbose: bool) -> str
 
 if __name__ == "__main__":
     import sys
-    print(build_native(force=True, verbose=True, dev="--dev" in sys.argv))
+    print(build_native(force=True, verbose=True))

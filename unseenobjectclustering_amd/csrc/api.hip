@@ -29,11 +29,7 @@ int EnvInt::get() {
 extern "C" {
 int uoc_version(void) { return 102; }
 int uoc_is_dev_build(void) {
-#ifdef UOC_DEV
-  return 1;
-#else
   return 0;
-#endif
 }
 /* What could make two ranks compute different bits: the library version, a development build, and (development builds
  * only) the values of the knobs that change rounding.  runner.run_sharded all-reduces it with the error flag. */
@@ -47,11 +43,6 @@ unsigned long long uoc_config_fingerprint(void) {
   };
   mix(uoc_version());
   mix(uoc_is_dev_build());
-  mix(UOC_DEV_KNOB("UOC_WINOGRAD_F", 4));
-  mix(UOC_DEV_KNOB("UOC_WINOGRAD_MIN_CIN", 64));
-  mix(UOC_DEV_KNOB("UOC_HC_QUAD", 1));
-  mix(UOC_DEV_KNOB("UOC_HC_VARIANT", 2));
-  mix(UOC_DEV_KNOB("UOC_HC_VB_TILES", 16));
   return h;
 }
 int uoc_reload_env(void) {

@@ -44,15 +44,9 @@ struct EnvInt {
   int get();
 };
 
-// Development knobs exist ONLY in -DUOC_DEV builds (python -m unseenobjectclustering_amd.build --dev -> libuoc_hip_dev.so, A/B
-// measurements through scripts/ab.sh).  The shipped library compiles each of them to its default, so no stray environment
-// variable on one rank can change a kernel choice — let alone a rounding — there.  What the shipped library still reads
-// from the environment is speed-only and listed in INTEGRATION.md.
-#ifdef UOC_DEV
-#define UOC_DEV_KNOB(name, def) ([] { static ::uoc::EnvInt e_(name, def); return e_.get(); }())
-#else
-#define UOC_DEV_KNOB(name, def) (def)
-#endif
+// The library has ONE implementation per step and no knob that selects a kernel or changes a rounding (the measured-and-
+// rejected alternates of rounds 1-5 live in the git history, HISTORY.md names the commits).  What it still reads from
+// the environment is speed-only and listed in INTEGRATION.md.
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

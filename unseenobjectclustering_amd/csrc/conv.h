@@ -26,14 +26,6 @@ struct ConvParams {
 
 int launch_conv(const ConvParams &p, hipStream_t st);
 
-#ifdef UOC_DEV
-// Winograd F(2x2,3x3) path (csrc/wino.hip; rounds 1-2, development builds only) for 3x3 stride-1 layers: U = transformed
-// weights [G][16][Cin/32][Cout][32] (launch_wino_weights), Vws = scratch of wino_v_floats() floats.
-bool wino_eligible(const ConvParams &p);
-size_t wino_v_floats(int G, int B, int H, int W, int d, int Cin);
-int launch_wino_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st);
-int launch_wino_conv(const ConvParams &p, const float *U, float *Vws, hipStream_t st);
-#endif
 
 // Winograd F(4x4,3x3) path (csrc/wino4.hip): U = transformed weights [G*36][Cout][Cin] (launch_wino4_weights, computed
 // in double), ws = scratch of wino4_ws_floats() floats (the V and M frequency planes).

@@ -32,193 +32,6 @@ __device__ __forceinline__ f32x4 mfma4c(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-#ifdef UOC_DEV   // the register-staged kernel of round 1: the shipped library runs the LDS-DMA kernel below for every shape
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, int VARIANT = 0>
-__global__ __launch_bounds__(WAVES_M *WAVES_N * 64) void conv_mfma_kernel(ConvParams p, int ntiles, int mtiles) {
-  constexpr int NT = WAVES_M * WAVES_N * 64;
-  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-  constexpr int TM = WM / 16, TN = WN / 16;
-  constexpr int RPP = NT / 8;  // rows staged per pass (8 float4 per 32-float row)
-  constexpr int APASS = (BM + RPP - 1) / RPP, BPASS = (BN + RPP - 1) / RPP;
-  static_assert(WM % 16 == 0 && WN % 16 == 0, "wave tile must be a multiple of 16x16");
-
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-
-  // XCD-aware work mapping: hardware places block b on XCD b % 8 (speed only, never correctness).
-  // Work items are ordered (group, n-tile, m-tile) and each XCD takes a CONTIGUOUS slice, so the
-  // blocks sharing one [BN x K] weight slab sit behind the same 4 MiB L2.
-  const int total = p.G * ntiles * mtiles;
-  const int per_xcd = (total + 7) >> 3;
-  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (work >= total) return;
-  const int g = work / (ntiles * mtiles);
-  const int rem = work - g * (ntiles * mtiles);
-  const int nt = rem / mtiles, mt = rem - nt * mtiles;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int HoWo = p.Ho * p.Wo;
-  const int M = p.B * HoWo;
-  const int Kc = STEM ? 32 : p.Cin;
-  const int T = STEM ? p.KH : p.KH * p.KW;
-  const int cpt = STEM ? 1 : p.Cin / BK;  // chunks per tap
-  const int nk = T * cpt;
-
-  const float *__restrict__ in = p.in + (size_t)g * p.B * p.H * p.W * p.Cin;
-  const float *__restrict__ w = p.w + (size_t)g * T * p.Cout * Kc;
-  const float *__restrict__ bias = p.bias ? p.bias + (size_t)g * p.Cout : nullptr;
-  const float *__restrict__ res = p.res ? p.res + (size_t)g * M * p.Cout : nullptr;
-  float *__restrict__ out = p.out + (size_t)g * M * p.Cout;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int t = lane & 15, q = lane >> 4;
-  const int lrow = tid >> 3, lcol = tid & 7;
-
-  int a_iy0[APASS], a_ix0[APASS], a_base[APASS];
-#pragma unroll
-  for (int j = 0; j < APASS; ++j) {
-    const int row = lrow + j * RPP;
-    const int m = m0 + row;
-    if (row < BM && m < M) {
-      const int b = m / HoWo;
-      const int r = m - b * HoWo;
-      const int oy = r / p.Wo, ox = r - oy * p.Wo;
-      a_iy0[j] = oy * p.stride - p.pad;
-      a_ix0[j] = ox * p.stride - p.pad;
-      a_base[j] = b * p.H * p.W * p.Cin;
-    } else {
-      a_iy0[j] = -(1 << 28);  // never in range
-      a_ix0[j] = 0;
-      a_base[j] = 0;
-    }
-  }
-
-  // Software pipeline (one barrier per K-chunk):
-  //   top of chunk kc: the h=0 operand fragments of chunk kc are already in registers (op0);
-  //   issue the global loads of chunk kc+1, prefetch the h=1 fragments (op1) from LDS, run the h=0
-  //   MFMAs (they hide both latencies), park chunk kc+1 in the other LDS stage, barrier, prefetch
-  //   chunk kc+1's h=0 fragments, run the h=1 MFMAs.
-  float4 ra[APASS], rb[BPASS];
-#pragma unroll
-  for (int j = 0; j < APASS; ++j) ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int j = 0; j < BPASS; ++j) rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-#define UOC_GLOAD(KN)                                                                                        \
-  {                                                                                                          \
-    const int cc_ = STEM ? 0 : (KN) / T; /* K order: cin slice outer, tap inner (L2 reuse of the slice) */ \
-    const int tap = (KN)-cc_ * T;                                                                            \
-    const int c0 = cc_ * BK;                                                                                 \
-    const int kh = STEM ? tap : tap / p.KW;                                                                  \
-    const int kw = STEM ? 0 : tap - kh * p.KW;                                                               \
-    _Pragma("unroll") for (int j = 0; j < APASS; ++j) {                                                      \
-      const int iy = a_iy0[j] + kh * p.dil;                                                                  \
-      const int ix = a_ix0[j] + (STEM ? lcol : kw * p.dil);                                                  \
-      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;                          \
-      const float *src = in + a_base[j] + (iy * p.W + ix) * p.Cin + (STEM ? 0 : c0 + 4 * lcol);              \
-      ra[j] = ok ? *reinterpret_cast<const float4 *>(src) : make_float4(0.f, 0.f, 0.f, 0.f);                 \
-    }                                                                                                        \
-    _Pragma("unroll") for (int j = 0; j < BPASS; ++j) {                                                      \
-      int row = lrow + j * RPP;                                                                              \
-      if (row >= BN) row = BN - 1; /* harmless duplicate load; the LDS store is guarded */                   \
-      rb[j] = *reinterpret_cast<const float4 *>(w + ((size_t)tap * p.Cout + n0 + row) * Kc + c0 + 4 * lcol); \
-    }                                                                                                        \
-  }
-#define UOC_LSTORE(STAGE)                                                                  \
-  {                                                                                        \
-    float *As_ = smem + (STAGE) * (BM + BN) * BKP;                                         \
-    float *Ws_ = As_ + BM * BKP;                                                           \
-    _Pragma("unroll") for (int j = 0; j < APASS; ++j) {                                    \
-      const int row = lrow + j * RPP;                                                      \
-      if (row < BM) *reinterpret_cast<float4 *>(As_ + row * BKP + 4 * lcol) = ra[j];       \
-    }                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < BPASS; ++j) {                                    \
-      const int row = lrow + j * RPP;                                                      \
-      if (row < BN) *reinterpret_cast<float4 *>(Ws_ + row * BKP + 4 * lcol) = rb[j];       \
-    }                                                                                      \
-  }
-#define UOC_FRAG(STAGE, HH, WA, XB)                                                                              \
-  {                                                                                                              \
-    const float *As_ = smem + (STAGE) * (BM + BN) * BKP;                                                         \
-    const float *Ws_ = As_ + BM * BKP;                                                                           \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) WA[j] =                                                       \
-        *reinterpret_cast<const float4 *>(Ws_ + (wn * WN + 16 * j + t) * BKP + 16 * (HH) + 4 * q);               \
-    _Pragma("unroll") for (int i = 0; i < TM; ++i) XB[i] =                                                       \
-        *reinterpret_cast<const float4 *>(As_ + (wm * WM + 16 * i + t) * BKP + 16 * (HH) + 4 * q);               \
-  }
-#define UOC_MFMA(WA, XB)                                                                                         \
-  {                                                                                                              \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[j][i] =    \
-        mfma4c(WA[j].x, XB[i].x, acc[j][i]);                                                                     \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[j][i] =    \
-        mfma4c(WA[j].y, XB[i].y, acc[j][i]);                                                                     \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[j][i] =    \
-        mfma4c(WA[j].z, XB[i].z, acc[j][i]);                                                                     \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i) acc[j][i] =    \
-        mfma4c(WA[j].w, XB[i].w, acc[j][i]);                                                                     \
-  }
-
-  f32x4 acc[TN][TM];
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  float4 wa0[TN], xb0[TM], wa1[TN], xb1[TM];
-  UOC_GLOAD(0)
-  UOC_LSTORE(0)
-  __syncthreads();
-  UOC_FRAG(0, 0, wa0, xb0)
-  if (VARIANT >= 3) UOC_FRAG(0, 1, wa1, xb1)
-  for (int kc = 0; kc < nk; ++kc) {
-    const int stage = kc & 1;
-    const bool more = kc + 1 < nk;
-    // VARIANT != 0 are timing ablations only (wrong results): 1 = no global loads, 2 = also no LDS
-    // stores / barrier, 3 = also no fragment reads (pure MFMA issue rate).
-    if (more && VARIANT < 1) UOC_GLOAD(kc + 1)
-    if (VARIANT < 3) UOC_FRAG(stage, 1, wa1, xb1)
-    UOC_MFMA(wa0, xb0)
-    if (VARIANT < 2) {
-      if (more) UOC_LSTORE(stage ^ 1)
-      __syncthreads();
-    }
-    if (more && VARIANT < 3) UOC_FRAG(stage ^ 1, 0, wa0, xb0)
-    UOC_MFMA(wa1, xb1)
-  }
-#undef UOC_GLOAD
-#undef UOC_LSTORE
-#undef UOC_FRAG
-#undef UOC_MFMA
-
-  // ---- epilogue: + folded-BN shift, + residual, ReLU; lane holds 4 consecutive couts of a pixel
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int co = n0 + wn * WN + 16 * j + 4 * q;
-    const float4 bv = bias ? *reinterpret_cast<const float4 *>(bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int m = m0 + wm * WM + 16 * i + t;
-      if (m < M) {
-        float4 v = make_float4(acc[j][i][0] + bv.x, acc[j][i][1] + bv.y, acc[j][i][2] + bv.z, acc[j][i][3] + bv.w);
-        if (res) {
-          const float4 rv = *reinterpret_cast<const float4 *>(res + (size_t)m * p.Cout + co);
-          v.x += rv.x;
-          v.y += rv.y;
-          v.z += rv.z;
-          v.w += rv.w;
-        }
-        if (p.relu) {
-          v.x = fmaxf(v.x, 0.f);
-          v.y = fmaxf(v.y, 0.f);
-          v.z = fmaxf(v.z, 0.f);
-          v.w = fmaxf(v.w, 0.f);
-        }
-        *reinterpret_cast<float4 *>(out + (size_t)m * p.Cout + co) = v;
-      }
-    }
-  }
-}
-
-#endif  // UOC_DEV
 
 // -------------------------------------------------------------------------------------------
 // Production variant: operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging,
@@ -565,37 +378,9 @@ static const TileCfg kCfgs[] = {
 constexpr int kNumCfg = sizeof(kCfgs) / sizeof(kCfgs[0]);
 constexpr int kNumCU = 256;
 
-#ifdef UOC_DEV
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool STEM, int VARIANT = 0>
-static int launch_cfg(const ConvParams &p, hipStream_t st, int kc) {
-  const int M = p.B * p.Ho * p.Wo;
-  const double taps = (double)p.KH * p.KW;
-  const double flops = 2.0 * M * p.Cout * (STEM ? 3.0 : (double)p.Cin) * taps * p.G;
-  const double bytes = 4.0 * p.G * ((double)p.B * p.H * p.W * (STEM ? 3 : p.Cin) + taps * p.Cout * (STEM ? 3 : p.Cin) +
-                                    (double)M * p.Cout * (p.res ? 2 : 1));
-  const ProfTag tag = {{p.prof_kc >= 0 ? p.prof_tag[0] : M, p.prof_kc >= 0 ? p.prof_tag[1] : p.Cin,
-                        p.prof_kc >= 0 ? p.prof_tag[2] : p.Cout, p.prof_kc >= 0 ? p.prof_tag[3] : p.dil}};
-  ProfScope prof(p.prof_kc >= 0 ? p.prof_kc : kc, st, p.prof_kc >= 0 ? p.prof_flops : flops, bytes, tag);
-  const int mtiles = (M + BM - 1) / BM, ntiles = p.Cout / BN;
-  const size_t lds = (size_t)2 * (BM + BN) * BKP * sizeof(float);
-  static DeviceOnce attr_set;
-  if (!attr_set.done()) {
-    UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, STEM, VARIANT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set.mark();
-  }
-  const int total = mtiles * ntiles * p.G;
-  hipLaunchKernelGGL((conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, STEM, VARIANT>), dim3(((total + 7) / 8) * 8),
-                     dim3(WAVES_M * WAVES_N * 64), lds, st, p, ntiles, mtiles);
-  UOC_LAUNCH_CHECK();
-  return UOC_OK;
-}
-#endif  // UOC_DEV
 
 static int pick_cfg(const ConvParams &p) {
-  const int forced = UOC_DEV_KNOB("UOC_CONV_CFG", -1);
   const int M = p.B * p.Ho * p.Wo;
-  if (forced >= 0 && forced < kNumCfg && p.Cout % kCfgs[forced].BN == 0) return forced;
   int best = -1;
   double best_cost = 0;
   for (int c = 0; c < kNumCfg; ++c) {
@@ -626,7 +411,6 @@ static const int kBmWide[4] = {96, 128, 160, 192};  // 2x4-wave families (wave t
 static const int kBmNarrow[3] = {64, 80, 96};       // 1x8 / 1x4-wave families (wave tile BM x 16)
 
 static int pick_bm(int M, int ntiles, int G, int BN, const int *cands, int n) {
-  if (UOC_DEV_KNOB("UOC_CONV_FIXED_TILE", 0)) return cands == kBmWide ? 160 : 80;   // dev A/B: always the 160 / 80 tile
   int best = cands[n - 1];
   double best_cost = -1;
   for (int i = 0; i < n; ++i) {
@@ -680,16 +464,6 @@ static int launch_choice(const ConvParams &p, hipStream_t st, Choice c) {
         }
     }
   }
-#ifdef UOC_DEV
-  else {
-    switch (c.cfg) {
-      case 0: return launch_cfg<160, 128, 2, 4, false>(p, st, KC_CONV_160x128);
-      case 1: return launch_cfg<80, 128, 1, 8, false>(p, st, KC_CONV_80x128);
-      case 2: return launch_cfg<160, 64, 2, 4, false>(p, st, KC_CONV_160x64);
-      case 3: return launch_cfg<80, 64, 1, 4, false>(p, st, KC_CONV_80x64);
-    }
-  }
-#endif
   set_error("conv: bad choice cfg=%d", c.cfg);
   return UOC_EINVAL;
 }
@@ -719,9 +493,7 @@ static void tune_cache_load() {
   while (g_ntuned < 256 && fscanf(f, "%d %d %d %d %d %d %d %d %d %d %d", &e.key.G, &e.key.B, &e.key.H, &e.key.W,
                                   &e.key.Cin, &e.key.Cout, &e.key.K, &e.key.stride, &e.key.dil, &e.choice.cfg,
                                   &e.choice.glds) == 11) {
-#ifndef UOC_DEV
     e.choice.glds = 1;   // a cache written by a development build may name the register-staged kernel
-#endif
     if (e.choice.cfg >= 0 && e.choice.cfg < kNumCfg) g_tuned[g_ntuned++] = e;
   }
   fclose(f);
@@ -746,14 +518,8 @@ static Choice choose(const ConvParams &p, hipStream_t st, int glds_default) {
     autotune = e ? atoi(e) : 1;
     tune_cache_load();
   }
-  const int pin_cfg = UOC_DEV_KNOB("UOC_CONV_CFG", -1);
-#ifdef UOC_DEV
-  const int pin_glds = UOC_DEV_KNOB("UOC_CONV_GLDS", -1);
-#else
-  const int pin_glds = 1;   // one kernel family: the tuner only chooses the tile
-#endif
-  Choice stat = {pick_cfg(p), pin_glds >= 0 ? pin_glds : glds_default};
-  if (!autotune || pin_cfg >= 0) return stat;
+  Choice stat = {pick_cfg(p), 1};   // one kernel family: the tuner only chooses the tile
+  if (!autotune) return stat;
   const TuneKey key = {p.G, p.B, p.H, p.W, p.Cin, p.Cout, p.KH, p.stride, p.dil};
   int nearest = -1;
   for (int i = 0; i < g_ntuned; ++i) {
@@ -774,8 +540,7 @@ static Choice choose(const ConvParams &p, hipStream_t st, int glds_default) {
   if (hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
     for (int cfg = 0; cfg < kNumCfg; ++cfg) {
       if (p.Cout % kCfgs[cfg].BN) continue;
-      for (int gl = 0; gl < 2; ++gl) {
-        if (pin_glds >= 0 && gl != pin_glds) continue;
+      for (int gl = 1; gl < 2; ++gl) {
         const Choice c = {cfg, gl};
         if (launch_choice(p, st, c) != UOC_OK) continue;  // warm-up (also sets the LDS attribute)
         (void)hipEventRecord(e0, st);
@@ -809,13 +574,10 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   UOC_REQUIRE(p.G >= 1 && p.B >= 1 && p.H >= 1 && p.W >= 1, "conv: bad shape");
   UOC_REQUIRE((long)p.B * p.H * p.W * p.Cin < (1l << 31) && (long)p.B * p.Ho * p.Wo * p.Cout < (1l << 31),
               "conv: tensor too large for 32-bit indexing");
-  const int use_glds = UOC_DEV_KNOB("UOC_CONV_GLDS", 1) != 0;  // dev A/B: 0 = the register-staged kernel
+  const int use_glds = 1;
   if (p.stem) {
     UOC_REQUIRE(p.Cin == 4 && p.KH == 7 && p.KW == 7 && p.stride == 2 && p.pad == 3 && p.dil == 1 && p.Cout == 64,
                 "conv: stem path is 7x7 s2 p3, NHWC4 -> 64 only");
-#ifdef UOC_DEV
-    if (!use_glds) return launch_cfg<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
-#endif
     return launch_glds<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
   }
   UOC_REQUIRE(p.Cin % BK == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, BK);
@@ -863,23 +625,6 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
       }
     return UOC_OK;
   }
-#ifdef UOC_DEV   // timing ablations (WRONG results): compiled only into development builds
-  static int variant = -1;
-  if (variant < 0) {
-    const char *e = getenv("UOC_CONV_VARIANT");  // timing ablations of the 160x128 kernel (dev only)
-    variant = e ? atoi(e) : 0;
-  }
-  if (variant >= 11 && pick_cfg(p) == 0) {  // 11..13: ablations of the LDS-DMA 160x128 kernel
-    if (variant == 11) return launch_glds<160, 128, 2, 4, false, 1>(p, st, KC_GLDS_160x128);
-    if (variant == 12) return launch_glds<160, 128, 2, 4, false, 2>(p, st, KC_GLDS_160x128);
-    return launch_glds<160, 128, 2, 4, false, 3>(p, st, KC_GLDS_160x128);
-  }
-  if (variant > 0 && pick_cfg(p) == 0) {
-    if (variant == 1) return launch_cfg<160, 128, 2, 4, false, 1>(p, st, KC_CONV_160x128);
-    if (variant == 2) return launch_cfg<160, 128, 2, 4, false, 2>(p, st, KC_CONV_160x128);
-    return launch_cfg<160, 128, 2, 4, false, 3>(p, st, KC_CONV_160x128);
-  }
-#endif
   const Choice ch = choose(p, st, use_glds);
   if (ch.cfg < 0) {
     set_error("conv: no tile configuration for Cout=%d", p.Cout);

@@ -1163,9 +1163,8 @@ struct MsWorkspace {
   size_t total;
 };
 
-// UOC_HC_VARIANT: 2 (default) = register-resident kernel, one wave per SIMD; 0 = LDS-fragment kernel (the only one for
-// 128-d fields).  (1 was round 2's two-waves-per-SIMD experiment, measured equal and removed: DESIGN.md.)
-static int hc_variant() { return UOC_DEV_KNOB("UOC_HC_VARIANT", 2) != 0 ? 2 : 0; }   // dev A/B only: the two kernels sum in different orders
+// 64-d fields run the register-resident kernel (one wave per SIMD), 128-d fields the LDS-fragment kernel.
+static int hc_variant() { return 2; }
 
 // Virtual blocks of a hill-climbing launch: a function of the field size ONLY (about 16 pixel tiles per wave, at most 256
 // blocks of 4 waves), so the fp32 summation order of the new seed positions is the same whether a field is clustered
@@ -1173,8 +1172,7 @@ static int hc_variant() { return UOC_DEV_KNOB("UOC_HC_VARIANT", 2) != 0 ? 2 : 0;
 // map could then depend on its launch-set mates.)
 static int hc_virtual_blocks(int n) {
   const int ntile = (n + 15) / 16;
-  // dev knob (changes the summation order, i.e. the last bits of the seeds): pixel tiles per wave and virtual block
-  const int tiles_per_wave = UOC_DEV_KNOB("UOC_HC_VB_TILES", 16) > 0 ? UOC_DEV_KNOB("UOC_HC_VB_TILES", 16) : 16;
+  const int tiles_per_wave = 16;   // part of the summation order (the last bits of the seeds): a constant
   int nvb = (ntile + 4 * tiles_per_wave - 1) / (4 * tiles_per_wave);
   if (nvb > 256) nvb = 256;
   if (nvb < 1) nvb = 1;
@@ -1184,8 +1182,6 @@ static int hc_virtual_blocks(int n) {
 // Physical blocks per field: the count p that minimises (rounds of CUs the grid needs) x (virtual blocks per physical
 // block); one 4-wave block per CU (register-resident kernel) or two (LDS-fragment kernel).
 static int hc_physical_blocks(int batch, int nvb, int per_cu) {
-  const int forced = UOC_DEV_KNOB("UOC_HC_BLOCKS", 0);   // dev: physical blocks per field
-  if (forced > 0) return forced < nvb ? forced : nvb;
   const int slots = (device_num_cu() > 0 ? device_num_cu() : 256) * per_cu;
   int best = 1;
   long best_cost = -1;
@@ -1276,9 +1272,8 @@ static int fps_persistent_plan(int batch, int n, int *bpi, int *nslots) {
   if (ns < 1) ns = 1;
   // Pack the field onto as few CUs as its pixels need (all FPP_SLOTS pixel slots of every lane: 480x640 on 150 instead of
   // 200 CUs).  The kernel is bound by the per-step grid exchange, not by its 64 FMAs per pixel, and the CUs it does not
-  // occupy run other streams' kernels meanwhile: 150.0 -> 158.3 frames/s sustained (round 3; UOC_FPS_PACK=0 restores
-  // the spread-out grid, 2 / 3 = at least that many pixels per lane).
-  const int pack = UOC_DEV_KNOB("UOC_FPS_PACK", FPP_SLOTS);
+  // occupy run other streams' kernels meanwhile: 150.0 -> 158.3 frames/s sustained (round 3).
+  const int pack = FPP_SLOTS;
   if (pack > ns) ns = pack < FPP_SLOTS ? pack : FPP_SLOTS;
   b = (n + FPP_THREADS * ns - 1) / (FPP_THREADS * ns);  // drop blocks that would own no pixel
   *bpi = b;
@@ -1303,8 +1298,14 @@ static FpsChain &fps_chain() {
   static FpsChain *c = new FpsChain();  // never destructed: static destruction order vs. the HIP runtime is undefined
   return *c;
 }
-// dev knob UOC_FPS_COOP=0: plain launch of the persistent grid (co-residency then rests on the plan + the event chain alone)
-static bool fps_cooperative() { return UOC_DEV_KNOB("UOC_FPS_COOP", 1) != 0; }
+// A stream that is being captured into a hipGraph (the one-frame-at-a-time replay path, fcn/graph_replay.py) gets a PLAIN
+// launch of the persistent grid and no event chain: a cooperative launch and a wait on an event recorded outside the
+// capture are not capturable.  Co-residency then rests on the plan (grid <= the device's resident capacity) and on the
+// caller replaying such graphs on ONE stream per device, with nothing else running beside them.
+static bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus s = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &s) == hipSuccess && s != hipStreamCaptureStatusNone;
+}
 
 static int run_select_seeds(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
                             int32_t *indices, const MsWorkspace &w, hipStream_t st) {
@@ -1329,8 +1330,7 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
     UOC_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int), st));
     // the LDS pixel slot is only touched when a lane owns more than FPP_RS pixels; without it the kernel needs no
     // dynamic LDS at all and can share a CU with another stream's convolution blocks (two frames in flight)
-    const bool lds_always = UOC_DEV_KNOB("UOC_FPS_LDS_ALWAYS", 0) != 0;  // dev: the round-1 launch shape
-    const size_t lds = (nslots > FPP_RS || lds_always) ? (size_t)FPP_LS * (C / 4) * FPP_THREADS * sizeof(float4) : 0;
+    const size_t lds = (nslots > FPP_RS) ? (size_t)FPP_LS * (C / 4) * FPP_THREADS * sizeof(float4) : 0;
     static DeviceOnce attr_set;
     if (!attr_set.done()) {
       UOC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_persistent_kernel),
@@ -1351,12 +1351,13 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
       // after the other; everything else on the two streams still overlaps.
       FpsChain &chain = fps_chain();
       std::lock_guard<std::mutex> lock(chain.mu);
-      hipEvent_t ev = g_fps_stream_ordering.load() ? chain.event() : nullptr;
+      const bool capturing = stream_is_capturing(st);
+      hipEvent_t ev = (g_fps_stream_ordering.load() && !capturing) ? chain.event() : nullptr;
       if (ev) UOC_HIP_CHECK(hipStreamWaitEvent(st, ev, 0));
       {
         ProfScope prof(KC_FPS_STEP, st, 2.0 * sub * (double)n * C * (m - 1), 4.0 * sub * (double)n * C,
                        ProfTag{{n, sub, bpi, nslots}});
-        if (fps_cooperative())
+        if (!capturing)
           e = hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&fps_persistent_kernel), dim3(sub * bpi),
                                          dim3(FPP_THREADS), args, (unsigned)lds, st);
         else
@@ -1434,24 +1435,8 @@ static void launch_hc(const float *X, int batch, int n, float *Z, int m, float k
       if constexpr (NH == 1) {
         if (reg) {
           const dim3 g(phys, batch), bdim(256);
-#ifdef UOC_DEV   // timing ablations of the ST = 7 kernel (wrong results): 1 = no exp arithmetic, 4 = S chains only, 5 = accumulate only
-          static int abl = -1;
-          if (abl < 0) {
-            const char *e = getenv("UOC_HC_ABLATE");
-            abl = e ? atoi(e) : 0;
-            if (abl) fprintf(stderr, "[uoc] UOC_HC_ABLATE=%d: hill climbing produces WRONG results (timing ablation)\n", abl);
-          }
-          auto go = [&](auto kern) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
-            hipLaunchKernelGGL(kern, g, bdim, lds_reg, st, X, n, Z, m, kappa, w.hc_partial, nvb);
-          };
-          if (ST == 7 && abl == 1) go(hc_iter_reg1_kernel<ST, (ST == 7 ? 1 : 0)>);
-          else if (ST == 7 && abl == 4) go(hc_iter_reg1_kernel<ST, (ST == 7 ? 4 : 0)>);
-          else if (ST == 7 && abl == 5) go(hc_iter_reg1_kernel<ST, (ST == 7 ? 5 : 0)>);
-          else
-#endif
           {
-            const int quad_ok = UOC_DEV_KNOB("UOC_HC_QUAD", 1);   // dev A/B: 0 = the last seed tile as a padded 16-seed tile (rounds 2-3a)
+            const int quad_ok = 1;   // the last <= 4 seeds run on the 4x4x1 MFMA instead of a padded 16-seed tile
             const int last = m - 16 * (ST - 1);      // seeds in the last tile
             if (quad_ok && ST >= 2 && last >= 1 && last <= 4) {
               static DeviceOnce attr_q;

@@ -24,9 +24,6 @@ struct ConvLayer {
   int Cin, Cout, K, stride, dil, pad, relu;
   bool has_bn, has_bias, stem;
   float *d_w = nullptr, *d_b = nullptr;  // [G][...]
-#ifdef UOC_DEV
-  float *d_U = nullptr;                  // Winograd F(2x2) weights [G][16][Cin/32][Cout][32] (eligible layers, wino_f == 2; dev builds)
-#endif
   float *d_U4 = nullptr;                 // Winograd F(4x4) weights [G*36][Cout][Cin] (eligible layers, wino_f == 4)
   size_t w_per_group = 0;
 };
@@ -44,11 +41,10 @@ struct uoc_net {
   int stem = -1, fc = -1;
   bool finalized = false;
   int device = -1;
-  // Which layers run as Winograd convolutions is a compile-time rule of the shipped library (the algorithms round
-  // differently; no environment variable may change a result).  Development builds can set both (UOC_WINOGRAD_MIN_CIN,
-  // UOC_WINOGRAD_F) for A/B measurements.
-  int wino_min_cin = 64;   // 3x3 stride-1 layers with Cin >= this run as Winograd convolutions; 0 = never (round 4: 64, was 128)
-  int wino_f = 4;          // output tile of the Winograd path: 4 = F(4x4,3x3) (csrc/wino4.hip), 2 = F(2x2,3x3) (csrc/wino.hip, dev)
+  // Which layers run as Winograd convolutions is a compile-time rule (the algorithms round differently; no environment
+  // variable may change a result).
+  const int wino_min_cin = 64;   // 3x3 stride-1 layers with Cin >= this run as Winograd convolutions (round 4: 64, was 128)
+  const int wino_f = 4;          // output tile of the Winograd path: F(4x4,3x3) (csrc/wino4.hip)
   int mode = UOC_NET_RGBD_ADD;
   int G = 2;  // backbones evaluated side by side (2 for RGBD 'add' and 'cat')
 };
@@ -186,12 +182,6 @@ static int finalize_layer(uoc_net *n, ConvLayer &L) {
       UOC_HIP_CHECK(hipMalloc(&L.d_U4, (size_t)G * 36 * L.Cout * L.Cin * sizeof(float)));
       if (int rc = launch_wino4_weights(L.d_w, L.d_U4, G, L.Cout, L.Cin, nullptr)) return rc;
     }
-#ifdef UOC_DEV
-    else {
-      UOC_HIP_CHECK(hipMalloc(&L.d_U, (size_t)G * 16 * L.Cout * L.Cin * sizeof(float)));
-      if (int rc = launch_wino_weights(L.d_w, L.d_U, G, L.Cout, L.Cin, nullptr)) return rc;
-    }
-#endif
     UOC_HIP_CHECK(hipDeviceSynchronize());
   }
   return UOC_OK;
@@ -237,16 +227,6 @@ static NetWs carve_net(void *base, int mode, int wino_f, int B, int H, int W) {
   // Winograd scratch: worst case over the layers that may use it (1/8 resolution, dilation 2 with 256 channels or
   // dilation 4 with 512 channels; also sized for 1/4 resolution x 64)
   size_t wv = 0;
-#ifdef UOC_DEV   // F(2x2): V[G][16][Cin/32][tiles][32]
-  if (wino_f != 4) {
-    wv = wino_v_floats(G, B, d.H3, d.W3, 4, 512);
-    const size_t wv3 = wino_v_floats(G, B, d.H3, d.W3, 2, 256), wv2 = wino_v_floats(G, B, d.H3, d.W3, 1, 128),
-                 wv1 = wino_v_floats(G, B, d.H2, d.W2, 1, 64);
-    if (wv3 > wv) wv = wv3;
-    if (wv2 > wv) wv = wv2;
-    if (wv1 > wv) wv = wv1;
-  }
-#endif
   if (wino_f == 4) {  // F(4x4): V and M frequency planes [G*36][tiles][Cin + Cout]
     const int cand[6][4] = {{3, 4, 512, 512}, {3, 4, 256, 512}, {3, 2, 256, 256}, {3, 2, 128, 256}, {3, 1, 128, 128}, {2, 1, 64, 64}};
     for (const auto &c : cand) {
@@ -288,9 +268,6 @@ static int run_conv(int G, const ConvLayer &L, const float *in, const float *res
                     int Ho, int Wo, hipStream_t st, float *wino_ws = nullptr) {
   const ConvParams p = conv_params(G, L, in, res, out, B, H, W, Ho, Wo);
   if (L.d_U4 && wino_ws && wino4_eligible(p)) return launch_wino4_conv(p, L.d_U4, wino_ws, st);
-#ifdef UOC_DEV
-  if (L.d_U && wino_ws && wino_eligible(p)) return launch_wino_conv(p, L.d_U, wino_ws, st);
-#endif
   return launch_conv(p, st);
 }
 
@@ -313,8 +290,6 @@ int uoc_net_create_mode(uoc_net **out, int mode) {
   n->mode = mode;
   n->G = (mode == UOC_NET_RGBD_ADD || mode == UOC_NET_RGBD_CAT) ? 2 : 1;
   build_graph(n);
-  n->wino_min_cin = UOC_DEV_KNOB("UOC_WINOGRAD_MIN_CIN", 64);          // dev A/B: 0 disables the Winograd path
-  n->wino_f = UOC_DEV_KNOB("UOC_WINOGRAD_F", 4) == 2 ? 2 : 4;           // dev A/B: the F(2x2,3x3) kernels of rounds 1-2
   *out = n;
   return UOC_OK;
 }
@@ -326,9 +301,6 @@ int uoc_net_destroy(uoc_net *n) {
   for (auto &L : n->layers) {
     if (L.d_w) (void)hipFree(L.d_w);
     if (L.d_b) (void)hipFree(L.d_b);
-#ifdef UOC_DEV
-    if (L.d_U) (void)hipFree(L.d_U);
-#endif
     if (L.d_U4) (void)hipFree(L.d_U4);
   }
   delete n;
@@ -469,26 +441,6 @@ int uoc_conv2d_nhwc_algo(const float *d_in, const float *d_w, const float *d_bia
     if (int rc = launch_wino4_weights(d_w, U4, G, Cout, Cin, st)) return rc;
     return launch_wino4_conv(p, U4, ws4, st);
   }
-#ifdef UOC_DEV
-  if (algo == UOC_CONV_WINOGRAD2) {
-    UOC_REQUIRE(wino_eligible(p), "conv2d: shape not eligible for Winograd F(2x2,3x3)");
-    static float *U = nullptr, *V = nullptr;
-    static size_t ucap = 0, vcap = 0;
-    const size_t un = (size_t)G * 16 * Cout * Cin, vn = wino_v_floats(G, B, H, W, dil, Cin);
-    if (un > ucap) {
-      if (U) (void)hipFree(U);
-      UOC_HIP_CHECK(hipMalloc(&U, un * sizeof(float)));
-      ucap = un;
-    }
-    if (vn > vcap) {
-      if (V) (void)hipFree(V);
-      UOC_HIP_CHECK(hipMalloc(&V, vn * sizeof(float)));
-      vcap = vn;
-    }
-    if (int rc = launch_wino_weights(d_w, U, G, Cout, Cin, st)) return rc;
-    return launch_wino_conv(p, U, V, st);
-  }
-#endif
   set_error("conv2d: unknown algorithm %d", algo);
   return UOC_EINVAL;
 }

@@ -29,9 +29,6 @@ constexpr int W4BK = 32;  // cin chunk (floats): one 128-byte row piece per DMA 
 #ifndef W4_OUT_MIN_BLOCKS
 #define W4_OUT_MIN_BLOCKS 2   // blocks per CU the output transform is compiled for: two waves per SIMD = at most 256 registers per lane (8 of them spill)
 #endif
-#ifndef W4_DEFAULT_WAVES
-#define W4_DEFAULT_WAVES 8   // waves per plane-GEMM block on the 128-wide tiles (see wino4_gemm_kernel)
-#endif
 
 // ---- elementwise kernels: thin grid-stride wrappers around the bodies in wino4_math.h ---------------------------
 __global__ __launch_bounds__(256) void wino4_weight_kernel(const float *__restrict__ w, float *__restrict__ U, int G,
@@ -451,46 +448,20 @@ static void pick_wino4_tile(int NT, int Cout, int planes, int &bm, int &bn, int 
 static int launch_wino4_gemm(const float *V, const float *U, float *Mo, int NT, int Cin, int Cout, int planes, hipStream_t st) {
   int bm, bn, nblocks;
   pick_wino4_tile(NT, Cout, planes, bm, bn, nblocks);
-#ifdef UOC_DEV
-  // dev knob UOC_WINO4_TILE = 1000 * BM + BN (e.g. 160128), through the atomic EnvInt cache (uoc_reload_env re-reads)
-  const int env_tile = UOC_DEV_KNOB("UOC_WINO4_TILE", 0);
-  if (env_tile > 0) {
-    const int a = env_tile / 1000, b = env_tile % 1000;
-    if ((b == 64 || b == 128 || b == 256) && Cout % b == 0) {
-      bm = a;
-      bn = b;
-      const int ncu = device_num_cu() > 0 ? device_num_cu() : 256;
-      const long items = (long)planes * ((NT + bm - 1) / bm) * (Cout / bn), S = (items + 7) / 8;
-      nblocks = 8 * (int)(S < ncu / 8 ? S : ncu / 8);
-    }
-  }
-#endif
-  // UOC_W4_PAIR (dev A/B): 0 = the 3-stage ring with one barrier per chunk (round 3) everywhere.  Measured per launch shape,
+  // Pair loop (4-stage ring, one barrier per two K-chunks) against the 3-stage ring with one barrier per chunk, per launch shape,
   // same box: layer4 383 -> 377 / 569 -> 551 / 533 -> 516 us, layer3 117.4 -> 115.8 / 165 -> 161 / 150.5 -> 147 us, layer2
   // equal, the 2-chunk items of layer1 45.0 -> 45.6 us (worse: they keep the single-chunk loop); class average 154 -> 151.5 us
   const int cpt = Cin / W4BK;
-  const bool pair = UOC_DEV_KNOB("UOC_W4_PAIR", 1) != 0 && cpt % 2 == 0 && cpt >= 4;
-  // waves per block: 4 (one per SIMD, wave tile BM/2 x BN/2) for the 128-wide tiles, 8 for the 64-wide ones (a 4-wave block
-  // would hold BN/2 = 32-wide wave tiles there, no better than today's); dev A/B: UOC_W4_WAVES = 8 restores round 4
-  const int nw = bn == 128 && UOC_DEV_KNOB("UOC_W4_WAVES", W4_DEFAULT_WAVES) == 4 ? 4 : 8;
+  const bool pair = cpt % 2 == 0 && cpt >= 4;
+  // 8 waves per block (two per SIMD: the younger wave's MFMAs cover the older one's vmcnt / barrier wait; the one-wave-per-SIMD
+  // variant NW = 4 measured 15-25 % slower in round 5, HISTORY.md)
 #define W4_CASE(A, B)                                                                                                \
   if (bm == A && bn == B)                                                                                            \
     return pair ? launch_wino4_gemm_t<A, B, true, 8>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st)                    \
                 : launch_wino4_gemm_t<A, B, false, 8>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
-#define W4_CASE4(A, B)                                                                                               \
-  if (bm == A && bn == B && nw == 4)                                                                                 \
-    return pair ? launch_wino4_gemm_t<A, B, true, 4>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st)                    \
-                : launch_wino4_gemm_t<A, B, false, 4>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
-  W4_CASE4(96, 128) W4_CASE4(128, 128) W4_CASE4(160, 128) W4_CASE4(192, 128)
-#ifdef UOC_DEV   // round-5 experiment (UOC_WINO4_TILE=160256): 256-wide block tile = wave tile 80 x 64 at 8 waves (0.1125 fragment reads per MFMA), 3-stage ring only
-  if (bn == 256 && bm == 160) return launch_wino4_gemm_t<160, 256, false, 8>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
-  if (bn == 256 && bm == 128) return launch_wino4_gemm_t<128, 256, false, 8>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
-  if (bn == 256 && bm == 96) return launch_wino4_gemm_t<96, 256, false, 8>(V, U, Mo, NT, Cin, Cout, planes, nblocks, st);
-#endif
   W4_CASE(96, 128) W4_CASE(128, 128) W4_CASE(160, 128) W4_CASE(192, 128)
   W4_CASE(96, 64) W4_CASE(128, 64) W4_CASE(160, 64) W4_CASE(192, 64)
 #undef W4_CASE
-#undef W4_CASE4
   set_error("winograd F(4x4): no GEMM tile %dx%d", bm, bn);
   return UOC_EINVAL;
 }
@@ -524,11 +495,10 @@ int launch_wino4_weights(const float *w, float *U, int G, int Cout, int Cin, hip
 
 // Grid of the two elementwise kernels: every thread owns one (tile, channel quad) item at a time; the grid is capped at
 // the blocks that are resident at once (2 per CU at ~200 VGPRs) so that all blocks walk equally long item ranges and
-// finish together instead of leaving a half-empty last round (UOC_W4_TGRID = blocks per CU, 0 = one block per 256 items).
+// finish together instead of leaving a half-empty last round.
 static long wino4_elem_blocks(long items) {
-  const int per_cu = UOC_DEV_KNOB("UOC_W4_TGRID", 0);
   long blocks = (items + 255) / 256;
-  const long cap = per_cu > 0 ? (long)per_cu * (device_num_cu() > 0 ? device_num_cu() : 256) : 16384;
+  const long cap = 16384;
   blocks = blocks < cap ? blocks : cap;
   return (blocks + 7) / 8 * 8;     // a multiple of 8: the input transform deals its blocks to the XCDs in contiguous eighths
 }
@@ -559,10 +529,7 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
 }
 
 // ---- the three stages of one layer ---------------------------------------------------------------------------------
-static int w4_vec() {   // channels per thread of the two elementwise kernels (dev A/B UOC_W4_VEC): 4 (float4) moves the most bytes per instruction
-  const int v = UOC_DEV_KNOB("UOC_W4_VEC", 4);
-  return v == 1 || v == 2 ? v : 4;
-}
+static int w4_vec() { return 4; }   // channels per thread of the two elementwise kernels: float4 moves the most bytes per instruction
 
 static int w4_stage_input(const ConvParams &p, const Wino4Geom &geo, float *V, hipStream_t st) {
   const double Mpix = (double)p.B * p.H * p.W;
@@ -570,13 +537,6 @@ static int w4_stage_input(const ConvParams &p, const Wino4Geom &geo, float *V, h
   const int vec = w4_vec();
   ProfScope prof(KC_WINO4_INPUT, st, 0.0, 4.0 * p.G * (Mpix * p.Cin + 36.0 * geo.NT * p.Cin), tag);
   const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cin / vec));
-#ifdef UOC_DEV
-  if (vec == 1)
-    hipLaunchKernelGGL(wino4_input_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
-  else if (vec == 2)
-    hipLaunchKernelGGL(wino4_input_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
-  else
-#endif
     hipLaunchKernelGGL(wino4_input_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, p.in, V, geo, p.G, p.Cin);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
@@ -586,39 +546,10 @@ static int w4_stage_gemm(const ConvParams &p, const Wino4Geom &geo, const float 
   const int planes = 36 * p.G;
   const double Mpix = (double)p.B * p.H * p.W;
   const ProfTag tag = {{geo.NT, p.Cin, p.Cout, p.dil}};
-  // 2 = the persistent plane-GEMM kernel; 1 (dev A/B) = one direct 1x1 "convolution" over 36*G groups
-  const int gemm_mode = UOC_DEV_KNOB("UOC_WINO4_GEMM", 2) == 1 ? 1 : 2;
   // algorithmic flops = the direct 3x3 convolution's; the matrix pipe executes 36/144 of them
   // (+ the padding of partial tiles); bytes: V and U read once, M written once
   const double gflops = 2.0 * Mpix * p.Cout * p.Cin * 9.0 * p.G;
   const double gbytes = 4.0 * planes * ((double)geo.NT * p.Cin + (double)p.Cout * p.Cin + (double)geo.NT * p.Cout);
-  if (gemm_mode == 1) {
-    ConvParams q;
-    q.in = V;
-    q.w = U;
-    q.bias = nullptr;
-    q.res = nullptr;
-    q.out = Mw;
-    q.G = planes;
-    q.B = 1;
-    q.H = 1;
-    q.W = geo.NT;
-    q.Cin = p.Cin;
-    q.Ho = 1;
-    q.Wo = geo.NT;
-    q.Cout = p.Cout;
-    q.KH = q.KW = 1;
-    q.stride = 1;
-    q.dil = 1;
-    q.pad = 0;
-    q.relu = 0;
-    q.stem = 0;
-    q.tune = p.tune;
-    q.prof_kc = KC_WINO4_GEMM;
-    q.prof_flops = gflops;
-    q.prof_tag[0] = geo.NT, q.prof_tag[1] = p.Cin, q.prof_tag[2] = p.Cout, q.prof_tag[3] = p.dil;
-    return launch_conv(q, st);
-  }
   ProfScope prof(KC_WINO4_GEMM, st, gflops, gbytes, tag);
   return launch_wino4_gemm(V, U, Mw, geo.NT, p.Cin, p.Cout, planes, st);
 }
@@ -629,13 +560,6 @@ static int w4_stage_output(const ConvParams &p, const Wino4Geom &geo, const floa
   const int vec = w4_vec();
   ProfScope prof(KC_WINO4_OUTPUT, st, 0.0, 4.0 * p.G * (36.0 * geo.NT * p.Cout + Mpix * p.Cout * (p.res ? 2 : 1)), tag);
   const long blocks = wino4_elem_blocks((long)p.G * geo.NT * (p.Cout / vec));
-#ifdef UOC_DEV
-  if (vec == 1)
-    hipLaunchKernelGGL(wino4_output_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
-  else if (vec == 2)
-    hipLaunchKernelGGL(wino4_output_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
-  else
-#endif
     hipLaunchKernelGGL(wino4_output_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, Mw, p.bias, p.res, p.out, geo, p.G, p.Cout, p.relu);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
