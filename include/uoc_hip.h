@@ -215,6 +215,17 @@ int uoc_roi_match_stats(const int32_t *d_labels_crop, const float *d_mask_crops,
 int uoc_roi_paste(const int32_t *d_labels_crop, const uoc_roi_table *d_table, const int32_t *d_map,
                   const int32_t *d_order, int K, int S, int H, int W, int32_t *d_refined, void *stream);
 
+/* match_label_crop (:116-179) entirely on the device (round 6): the statistics of uoc_roi_match_stats, then the ROI paint
+ * order — sorted(key = mean depth | box area, reverse=True) with Python's stable-sort semantics, NaN keys included for
+ * K < 64 (csrc/roi.hip restates CPython's list.sort for short lists) — the running renumbering of kept clusters, and the
+ * paste of uoc_roi_paste.  No host round trip.  d_keep (nullable) [K][128] receives the keep table, d_plan (nullable)
+ * [K + K*128] the paint order followed by the id map.  d_status (nullable): bit 0 is OR-ed in when some key is NaN and
+ * K >= 64 — the one case not restated here; d_refined is then painted in index order and the caller re-does the ordering
+ * on the host (uoc_roi_match_stats + uoc_roi_paste). */
+int uoc_roi_match(const int32_t *d_labels_crop, const float *d_mask_crops, const float *d_xyz_crops,
+                  const uoc_roi_table *d_table, int K, int S, int H, int W, int32_t *d_refined, int32_t *d_keep,
+                  int32_t *d_plan, int32_t *d_status, void *d_ws, size_t ws_bytes, void *stream);
+
 /* Frame-parallel runner (no reference counterpart; SURVEY 8(e): the gathered block is uint8 like the ROS consumer's cast,
  * ros/test_images_segmentation.py:165): d_out[i] = (uint8) d_labels[i] for i < n, *d_top = max(*d_top, max_i d_labels[i])
  * (the caller checks once per block that no id exceeded 255). */

@@ -206,3 +206,63 @@ def test_batch_of_two_and_no_crop_network(device):
     np.random.seed(RNG_SEED)
     out2, none = TD.test_sample(dict(image_color=img, depth=dep), lambda i, l, d: s1(i, l, d).to(device), None)
     assert none is None and np.array_equal(out2.numpy(), want_label.numpy())
+
+
+def _order_case(rng, K, S, nan_rate, tie_rate):
+    """Random crop clusterings of K ROIs with mean depths that tie and that are NaN (every kept pixel at z = 0)."""
+    SS = S * S
+    labels = torch.from_numpy(rng.randint(0, 4, size=(K, SS)).astype(np.int32))
+    mask = torch.from_numpy((rng.rand(K, S, S) < 0.7).astype(np.float32))
+    zval = rng.choice(np.round(rng.rand(max(2, K // 3)) + 0.5, 2), size=K) if tie_rate else rng.rand(K) + 0.5
+    depth = torch.zeros(K, 3, S, S)
+    for k in range(K):
+        depth[k, 2] = 0.0 if rng.rand() < nan_rate else float(zval[k])
+    t = TD._native.RoiTable()
+    t.K = K
+    for k in range(K):
+        x0, y0 = rng.randint(0, 40), rng.randint(0, 30)
+        t.box[k][0], t.box[k][1], t.box[k][2], t.box[k][3] = x0, y0, x0 + rng.randint(3, 24), y0 + rng.randint(3, 18)
+        t.label[k] = k + 1
+    return labels, mask, depth, t
+
+
+@pytest.mark.parametrize("with_depth", [True, False])
+def test_device_roi_order_is_pythons_sorted(device, with_depth):
+    """uoc_roi_match (round 6: ROI paint order + renumbering on the device) against the host path it replaces — the
+    statistics read back, Python's own sorted(key=0-dim tensors, reverse=True), uoc_roi_paste — on random cases with
+    tied keys and NaN keys (lib/fcn/test_dataset.py:129-163; NaN: torch.mean of an empty selection, :135).  K < 64 covers
+    CPython's short-list algorithm (count_run + binary insertion) that the kernel restates for NaN keys; K >= 64
+    without NaN the rank sort; K >= 64 WITH NaN must raise the status flag instead of guessing."""
+    cfg.device = device
+    rng = np.random.RandomState(11)
+    old = cfg.TRAIN.SYN_CROP_SIZE
+    cfg.TRAIN.SYN_CROP_SIZE = 8
+    H, W = 64, 72
+    try:
+        cases = [(K, nan, tie) for K in (1, 2, 3, 5, 8, 13, 31, 63) for nan in (0.0, 0.3, 0.9) for tie in (0, 1)]
+        cases += [(64, 0.0, 1), (100, 0.0, 0), (127, 0.0, 1)]
+        for K, nan_rate, tie in cases:
+            for rep in range(3 if K < 64 else 1):
+                labels, mask, depth, t = _order_case(rng, K, 8, nan_rate if with_depth else 0.0, tie)
+                table = torch.frombuffer(bytearray(bytes(t)), dtype=torch.uint8).to(device)
+                lab_d, mask_d = labels.to(device), mask.to(device)
+                dep_d = depth.to(device) if with_depth else None
+                want, keep_w = TD._match_host_order(lab_d, mask_d, dep_d, table, K, H, W, device)
+                got, keep_g = TD._match_device(lab_d, mask_d, dep_d, table, K, H, W, device, want_keep=True)
+                assert not TD._order_needs_host(device), (K, nan_rate, tie)
+                assert torch.equal(keep_w.cpu(), keep_g.cpu())
+                assert torch.equal(want.cpu(), got.cpu()), (K, nan_rate, tie, rep)
+        if with_depth:
+            labels, mask, depth, t = _order_case(rng, 70, 8, 0.5, 0)
+            table = torch.frombuffer(bytearray(bytes(t)), dtype=torch.uint8).to(device)
+            TD._match_device(labels.to(device), mask.to(device), depth.to(device), table, 70, H, W, device)
+            assert TD._order_needs_host(device), "NaN keys with >= 64 ROIs must be flagged for the host path"
+            assert not TD._order_needs_host(device), "the flag is cleared by reading it"
+            # ... and match_label_crop (the reference-surface entry) takes that path by itself
+            rois = torch.tensor([[t.box[k][i] for i in range(4)] for k in range(70)], dtype=torch.float32)
+            init = torch.zeros(1, H, W)
+            got, _ = TD.match_label_crop(init, labels.view(70, 8, 8).float().to(device), mask.to(device), rois, depth.to(device))
+            want, _ = TD._match_host_order(labels.to(device), mask.to(device), depth.to(device), table, 70, H, W, device)
+            assert torch.equal(got[0].to(torch.int32).cpu().view(-1), want.cpu())
+    finally:
+        cfg.TRAIN.SYN_CROP_SIZE = old

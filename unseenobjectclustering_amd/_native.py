@@ -77,7 +77,8 @@ def _declare(lib):
     lib.uoc_roi_match_stats.argtypes = [P, P, P, c_int, c_int, P, P, P, c_size_t, P]
     lib.uoc_roi_paste.argtypes = [P, P, P, P, c_int, c_int, c_int, c_int, P, P]
     lib.uoc_labels_to_u8.argtypes = [P, ctypes.c_long, P, P, P]
-    for name in ("uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats", "uoc_roi_paste", "uoc_labels_to_u8"):
+    lib.uoc_roi_match.argtypes = [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_size_t, P]
+    for name in ("uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats", "uoc_roi_paste", "uoc_labels_to_u8", "uoc_roi_match"):
         getattr(lib, name).restype = c_int
     lib.uoc_lzf_decompress.argtypes = [P, c_size_t, P, c_size_t]
     lib.uoc_lzf_decompress.restype = ctypes.c_long
@@ -99,7 +100,7 @@ EXPORTED_SYMBOLS = (
     "uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",
     "uoc_net_forward", "uoc_conv2d_nhwc", "uoc_conv2d_nhwc_algo",
     "uoc_roi_workspace_bytes", "uoc_prep_rgbd", "uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats",
-    "uoc_roi_paste", "uoc_labels_to_u8", "uoc_eval_workspace_bytes", "uoc_eval_pair_stats", "uoc_lzf_decompress", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
+    "uoc_roi_paste", "uoc_roi_match", "uoc_labels_to_u8", "uoc_eval_workspace_bytes", "uoc_eval_pair_stats", "uoc_lzf_decompress", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
 )
 
 
@@ -162,6 +163,18 @@ def stream_key(device):
     flight on different streams never share a workspace."""
     import torch
     return (device.type, device.index, int(torch.cuda.current_stream(device).cuda_stream))
+
+
+_retired = []
+GRAPHS_ALIVE = 0          # captured hipGraphs in this process (fcn/graph_replay.py)
+
+
+def retire(t):
+    """A per-stream scratch buffer that is being replaced by a larger one.  Captured hipGraphs bake device addresses, so
+    once any graph exists the old buffer is kept alive (a bounded leak: buffers grow geometrically / by ROI count)
+    instead of going back to the allocator."""
+    if t is not None and GRAPHS_ALIVE > 0:
+        _retired.append(t)
 
 
 def prof_enable(on: bool):

@@ -50,6 +50,13 @@ struct EnvInt {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// True while `st` is being captured into a hipGraph (fcn/graph_replay.py): nothing that synchronises, times or launches
+// cooperatively may run then.
+static inline bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus s = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &s) == hipSuccess && s != hipStreamCaptureStatusNone;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Per-device one-time state.  hipFuncSetAttribute (dynamic LDS above 64 KB) applies to the CURRENT device's copy of a

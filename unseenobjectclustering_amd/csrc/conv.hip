@@ -531,7 +531,7 @@ static Choice choose(const ConvParams &p, hipStream_t st, int glds_default) {
     // same layer, other batch: reuse if the tile is still legal, never re-tune mid-stream
     return g_tuned[nearest].choice;
   }
-  if (g_ntuned >= 256 || !p.tune) return stat;
+  if (g_ntuned >= 256 || !p.tune || stream_is_capturing(st)) return stat;   // the tuner times launches with events: never inside a capture
   const bool prof_was = g_prof_enabled;
   g_prof_enabled = false;
   hipEvent_t e0, e1;

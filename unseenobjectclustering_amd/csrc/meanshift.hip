@@ -1302,10 +1302,6 @@ static FpsChain &fps_chain() {
 // launch of the persistent grid and no event chain: a cooperative launch and a wait on an event recorded outside the
 // capture are not capturable.  Co-residency then rests on the plan (grid <= the device's resident capacity) and on the
 // caller replaying such graphs on ONE stream per device, with nothing else running beside them.
-static bool stream_is_capturing(hipStream_t st) {
-  hipStreamCaptureStatus s = hipStreamCaptureStatusNone;
-  return hipStreamIsCapturing(st, &s) == hipSuccess && s != hipStreamCaptureStatusNone;
-}
 
 static int run_select_seeds(const float *X, int batch, int n, int m, const int32_t *first, float *seeds,
                             int32_t *indices, const MsWorkspace &w, hipStream_t st) {

@@ -219,6 +219,130 @@ __global__ __launch_bounds__(1024) void crop_meanz_kernel(const int *__restrict_
   }
 }
 
+// ROI paint order and global renumbering on the device (match_label_crop :129-163) — round 6: replaces the host's
+// sorted() between a device->host read of the statistics and a host->device upload of the plan.
+//   key[k]   = mean depth of ROI k (:129-136), or its box area as float32 without depth (:138-146)
+//   order    = sorted(range(K), key=key, reverse=True): Python's stable sort — equal keys keep their index order.
+//              Without NaN keys `<` is a strict weak order and every stable sort gives the same list: a rank sort.  With
+//              NaN keys (`torch.mean` of an empty selection, :135) every comparison is false and the result is whatever
+//              CPython's list.sort does; for K < 64 that is reverse, count_run, binary insertion sort, reverse
+//              (Objects/listobject.c, minrun = n below 64), restated here step by step.  NaN keys AND K >= 64 (merges with
+//              galloping) raise bit 0 of *status instead and the caller orders on the host.
+//   map[k][c] = running count over the kept clusters c of the ROIs in paint order (:156-163), 0 = dropped.
+// One block of 128 threads.
+struct KeyIdx {
+  float key;
+  int idx;
+};
+__device__ __forceinline__ bool key_lt(const KeyIdx &a, const KeyIdx &b) { return a.key < b.key; }   // the 0-dim tensors' `<`
+
+__device__ void cpython_sort_small(KeyIdx *a, int n) {   // list.sort(reverse=True) for n < 64, comparisons `<` only
+  auto rev = [&](int lo, int hi) {   // reverse a[lo:hi]
+    for (--hi; lo < hi; ++lo, --hi) {
+      const KeyIdx t = a[lo];
+      a[lo] = a[hi];
+      a[hi] = t;
+    }
+  };
+  rev(0, n);
+  if (n >= 2) {
+    int run = 2, lo;   // count_run
+    const bool desc = key_lt(a[1], a[0]);
+    if (desc) {
+      for (lo = 2; lo < n; ++lo, ++run)
+        if (!key_lt(a[lo], a[lo - 1])) break;
+    } else {
+      for (lo = 2; lo < n; ++lo, ++run)
+        if (key_lt(a[lo], a[lo - 1])) break;
+    }
+    if (desc) rev(0, run);
+    for (int start = run; start < n; ++start) {   // binarysort(lo = 0, hi = n, start = run)
+      int l = 0, r = start;
+      const KeyIdx pivot = a[start];
+      do {
+        const int p = l + ((r - l) >> 1);
+        if (key_lt(pivot, a[p]))
+          r = p;
+        else
+          l = p + 1;
+      } while (l < r);
+      for (int p = start; p > l; --p) a[p] = a[p - 1];
+      a[l] = pivot;
+    }
+  }
+  rev(0, n);
+}
+
+__global__ __launch_bounds__(NL) void roi_order_kernel(const int *__restrict__ keep, const float *__restrict__ meanz,
+                                                       const uoc_roi_table *__restrict__ table, int K,
+                                                       int *__restrict__ order, int *__restrict__ map,
+                                                       int *__restrict__ status) {
+  __shared__ KeyIdx a[NL];
+  __shared__ int ord[NL], nk[NL], base[NL];
+  __shared__ int s_nan;
+  const int t = threadIdx.x;
+  if (t == 0) s_nan = 0;
+  __syncthreads();
+  float key = 0.f;
+  if (t < K) {
+    if (meanz) {
+      key = meanz[t];
+    } else {  // roi_size = (y_max - y_min + 1) * (x_max - x_min + 1) on the float32 rois (:139-146)
+      const float x0 = (float)table->box[t][0], y0 = (float)table->box[t][1];
+      const float x1 = (float)table->box[t][2], y1 = (float)table->box[t][3];
+      key = __fmul_rn(y1 - y0 + 1.f, x1 - x0 + 1.f);
+    }
+    a[t].key = key;
+    a[t].idx = t;
+    if (key != key) atomicOr(&s_nan, 1);
+    int c = 0;
+    for (int l = 0; l < NL; ++l) c += keep[t * NL + l] != 0 ? 1 : 0;
+    nk[t] = c;
+  }
+  __syncthreads();
+  if (!s_nan) {
+    if (t < K) {
+      int pos = 0;
+      for (int j = 0; j < K; ++j) {
+        const float kj = a[j].key;
+        pos += (kj > key || (kj == key && j < t)) ? 1 : 0;
+      }
+      ord[pos] = t;
+    }
+  } else if (t == 0) {
+    if (K < 64) {
+      cpython_sort_small(a, K);
+      for (int j = 0; j < K; ++j) ord[j] = a[j].idx;
+    } else {
+      if (status) atomicOr(status, 1);
+      for (int j = 0; j < K; ++j) ord[j] = j;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    int running = 0;
+    for (int j = 0; j < K; ++j) {
+      const int i = ord[j];
+      base[i] = running;
+      running += nk[i];
+      order[j] = i;
+    }
+  }
+  __syncthreads();
+  // thread t = crop cluster id t: its rank among the kept clusters of ROI i (ascending id, like torch.unique :156)
+  __shared__ int wave0[NL];
+  for (int i = 0; i < K; ++i) {
+    const int kp = keep[i * NL + t] != 0 ? 1 : 0;
+    const unsigned long long m = __ballot(kp);
+    const int lane = t & 63;
+    const int below = __popcll(m & ((1ull << lane) - 1ull));
+    if (t == 0) wave0[i] = __popcll(m);   // kept clusters with id < 64
+    __syncthreads();
+    const int rank = below + (t >= 64 ? wave0[i] : 0);
+    map[i * NL + t] = kp ? base[i] + rank + 1 : 0;
+  }
+}
+
 // refined[p] = relabelled crop cluster of the LAST ROI (in paint order) covering p with a kept
 // cluster; 0 otherwise (:165-177; nearest resize back to the ROI size).
 __global__ __launch_bounds__(256) void paste_kernel(const int *__restrict__ labels_crop,
@@ -274,6 +398,9 @@ struct RoiWs {
   int *lut;    // [128]
   int *cnt;    // [127][128]
   int *ov;     // [127][128]
+  int *keep;   // [127][128]   (uoc_roi_match)
+  float *meanz;  // [128]
+  int *plan;   // [128] paint order + [127][128] id map
   size_t total;
 };
 static RoiWs carve_roi(void *base) {
@@ -288,6 +415,9 @@ static RoiWs carve_roi(void *base) {
   w.lut = (int *)take(NL * sizeof(int));
   w.cnt = (int *)take((size_t)NL * NL * sizeof(int));
   w.ov = (int *)take((size_t)NL * NL * sizeof(int));
+  w.keep = (int *)take((size_t)NL * NL * sizeof(int));
+  w.meanz = (float *)take(NL * sizeof(float));
+  w.plan = (int *)take((size_t)(NL + NL * NL) * sizeof(int));
   w.total = off;
   return w;
 }
@@ -417,6 +547,31 @@ int uoc_roi_paste(const int32_t *d_labels_crop, const uoc_roi_table *d_table, co
   UOC_REQUIRE(K >= 1 && K < NL, "K=%d out of range", K);
   hipLaunchKernelGGL(paste_kernel, dim3(grid_for(H * W)), dim3(256), 0, (hipStream_t)stream, d_labels_crop, d_table,
                      d_map, d_order, K, S, H, W, d_refined);
+  UOC_LAUNCH_CHECK();
+  return UOC_OK;
+}
+
+int uoc_roi_match(const int32_t *d_labels_crop, const float *d_mask_crops, const float *d_xyz_crops,
+                  const uoc_roi_table *d_table, int K, int S, int H, int W, int32_t *d_refined, int32_t *d_keep,
+                  int32_t *d_plan, int32_t *d_status, void *d_ws, size_t ws_bytes, void *stream) {
+  UOC_REQUIRE(d_labels_crop && d_mask_crops && d_table && d_refined && d_ws, "null pointer");
+  UOC_REQUIRE(K >= 1 && K < NL && S >= 1 && H >= 1 && W >= 1, "K=%d S=%d out of range", K, S);
+  RoiWs w = carve_roi(d_ws);
+  UOC_REQUIRE(ws_bytes >= w.total, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  int *keep = d_keep ? d_keep : w.keep;
+  int *plan = d_plan ? d_plan : w.plan;
+  UOC_HIP_CHECK(hipMemsetAsync(w.cnt, 0, (size_t)K * NL * sizeof(int), st));
+  UOC_HIP_CHECK(hipMemsetAsync(w.ov, 0, (size_t)K * NL * sizeof(int), st));
+  int gb = (S * S + 255) / 256;
+  if (gb > 64) gb = 64;
+  hipLaunchKernelGGL(crop_stats_kernel, dim3(gb, K), dim3(256), 0, st, d_labels_crop, d_mask_crops, S * S, w.cnt, w.ov);
+  hipLaunchKernelGGL(crop_meanz_kernel, dim3(K), dim3(1024), 0, st, d_labels_crop, d_xyz_crops, S * S, w.cnt, w.ov, keep,
+                     w.meanz);
+  hipLaunchKernelGGL(roi_order_kernel, dim3(1), dim3(NL), 0, st, keep, d_xyz_crops ? w.meanz : (const float *)nullptr,
+                     d_table, K, plan, plan + K, d_status);
+  hipLaunchKernelGGL(paste_kernel, dim3(grid_for(H * W)), dim3(256), 0, st, d_labels_crop, d_table, plan + K, plan, K, S,
+                     H, W, d_refined);
   UOC_LAUNCH_CHECK();
   return UOC_OK;
 }

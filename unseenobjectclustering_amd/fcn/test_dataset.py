@@ -258,13 +258,74 @@ def _paste(labels_crop_i32, table_dev, table_host, stats_h, has_depth, K, H, W, 
     return refined
 
 
-def _match(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev):
-    """labels_crop_i32 [K, S*S] int32 (device) -> refined int32 [H*W] (device), keep table (device)."""
+_order_status = {}
+
+
+def _status_word(dev) -> torch.Tensor:
+    """Per-stream sticky device flag of uoc_roi_match (bit 0: NaN sort keys with >= 64 ROIs — the one ordering case the
+    device kernel does not restate; the caller then orders on the host)."""
+    key = _native.stream_key(dev)
+    if key not in _order_status:
+        _order_status[key] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return _order_status[key]
+
+
+def _match_device(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev, want_keep=False):
+    """match_label_crop (:116-179) with no host round trip (round 6): statistics, ROI paint order (Python's
+    sorted(reverse=True) semantics restated on the device), renumbering and paste in one call (uoc_roi_match).
+    -> refined int32 [H*W] (device), keep table [K,128] (device) or None."""
+    S = cfg.TRAIN.SYN_CROP_SIZE
+    L = _native.lib()
+    ws = _ws(dev)
+    refined = torch.empty((H * W,), dtype=torch.int32, device=dev)
+    keep = torch.empty((K, MAX_LABELS), dtype=torch.int32, device=dev) if want_keep else None
+    status = _status_word(dev)
+    with torch.cuda.device(dev):
+        rc = L.uoc_roi_match(_native.ptr(labels_crop_i32), _native.ptr(mask_crops), _native.ptr(depth_crops), _native.ptr(table),
+                             K, S, H, W, _native.ptr(refined), _native.ptr(keep), None, _native.ptr(status), _native.ptr(ws),
+                             ws.numel(), _native.stream_ptr(dev))
+    _native.check(rc, "uoc_roi_match")
+    return refined, keep
+
+
+def _order_needs_host(dev) -> bool:
+    """Reads and clears the sticky ordering flag of this stream (synchronises)."""
+    status = _status_word(dev)
+    flagged = int(status.item()) != 0
+    if flagged:
+        status.zero_()
+    return flagged
+
+
+def _finish_block(dev):
+    """End of a block of frames whose per-frame checks were deferred (the frame-parallel runner): the clustering status
+    (uoc_ms_check) and the ordering flag of every stream of `dev`."""
+    _check_clustering(dev)
+    flagged = False
+    for key, status in _order_status.items():
+        if key[:2] == (dev.type, dev.index) and int(status.item()) != 0:
+            status.zero_()
+            flagged = True
+    if flagged:
+        raise HostOrderNeeded("a frame had NaN ROI sort keys with >= 64 ROIs: re-run with the ROI ordering on the host")
+
+
+def _match_host_order(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev):
+    """The same with the ROI ordering on the host (Python's own sorted on the statistics read back): the fallback for NaN
+    keys with >= 64 ROIs, and the path of rounds 1-5."""
     stats = _match_stats(labels_crop_i32, mask_crops, depth_crops, K, dev)
     stats_h = stats.cpu()
     table_host = _read_table(table) if depth_crops is None else None
     refined = _paste(labels_crop_i32, table, table_host, stats_h, depth_crops is not None, K, H, W, dev)
     return refined, stats[:K * MAX_LABELS].view(K, MAX_LABELS)
+
+
+def _match(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev):
+    """labels_crop_i32 [K, S*S] int32 (device) -> refined int32 [H*W] (device), keep table (device)."""
+    refined, keep = _match_device(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev, want_keep=True)
+    if _order_needs_host(dev):
+        return _match_host_order(labels_crop_i32, mask_crops, depth_crops, table, K, H, W, dev)
+    return refined, keep
 
 
 def match_label_crop(initial_masks, labels_crop, out_label_crop, rois, depth_crop):
@@ -298,22 +359,30 @@ def test_sample(sample, network, network_crop):
     return _run_frame(sample, network, network_crop, DEPTH_FILTER)
 
 
+FORCE_HOST_ORDER = False      # True: ROI ordering on the host (rounds 1-5; the fallback for NaN keys with >= 64 ROIs)
+
+
+class HostOrderNeeded(_native.NativeError):
+    """A frame of the block had NaN sort keys with >= 64 ROIs: the device ordering does not restate that case, the
+    caller re-runs with FORCE_HOST_ORDER (runner.run_sharded does)."""
+
+
 class FrameJob:
-    """One frame on its way through the two-stage path, cut at the two points where the host needs a small result
-    from the device (the number of ROIs; which crop clusters to keep and in which order to paint the ROIs):
+    """One frame on its way through the two-stage path, cut at the ONE point where the host needs a small result from
+    the device (the number of ROIs, which sizes the stage-2 launches):
 
         stage1  embed, cluster, depth filter + ROI table          -> async D2H of the table
-        stage2  (needs K) crop, embed + cluster the K crops, match statistics -> async D2H of the statistics
-        stage3  (needs the statistics) host ordering, paste
+        stage2  (needs K) crop, embed + cluster the K crops, match statistics, ROI order + renumbering + paste (device)
 
-    `_run_frame` runs the three stages back to back; runner.run_pipelined keeps several jobs in flight, each on its
-    own stream, so that one frame's latency-bound phases (farthest-point sampling, seed components, glue, the reads)
-    overlap another frame's convolutions.  Results do not depend on the interleaving: every job draws its first seeds
-    from its own `rng`."""
+    Round 6: the second cut of rounds 1-5 (statistics to the host, Python's sorted, plan back to the device) is gone —
+    uoc_roi_match orders on the device.  With host_order=True (FORCE_HOST_ORDER) the old cut is back as stage3.
+    `_run_frame` runs the stages back to back; the pipelined runner keeps several FrameGroupJobs in flight.  Results do
+    not depend on the interleaving: every job draws its first seeds from its own `rng`."""
 
-    def __init__(self, sample, network, network_crop, depth_threshold, rng=None):
+    def __init__(self, sample, network, network_crop, depth_threshold, rng=None, host_order=None):
         self.sample, self.network, self.network_crop = sample, network, network_crop
         self.depth_threshold, self.rng = depth_threshold, rng
+        self.host_order = FORCE_HOST_ORDER if host_order is None else host_order
         self.K = 0
         self.labels = self.refined = None
 
@@ -356,6 +425,15 @@ class FrameJob:
             self.host.table.copy_(self.table, non_blocking=True)
             self.host.table_ready.record(torch.cuda.current_stream(dev))
 
+    def _set_refined(self, refined):
+        dev, H, W, B = self.dev, self.H, self.W, self.B
+        out = refined.view(1, H, W)
+        if B > 1:    # match_label_crop returns zeros_like(initial_masks) with only item 0 painted (:153,:176-177)
+            full = torch.zeros((B, H, W), dtype=refined.dtype, device=dev)
+            full[0] = out[0]
+            out = full
+        self.refined = out
+
     def stage2(self):
         if self.network_crop is None:
             return
@@ -369,24 +447,28 @@ class FrameJob:
         features_crop = _detach_keep_planes(self.network_crop(rgb_crop, mask_crop, depth_crop))     # :259
         self.labels_crop, _ = _cluster_device(features_crop, rng=self.rng)      # K fields, one launch set
         self.has_depth = depth_crop is not None
+        self.mask_crop, self.depth_crop = mask_crop, depth_crop       # kept for the host-order fallback
+        if not self.host_order:
+            refined, _ = _match_device(self.labels_crop, mask_crop, depth_crop, self.table, K, H, W, dev)
+            self._set_refined(refined)
+            return
         stats = _match_stats(self.labels_crop, mask_crop, depth_crop, K, dev)
         self.host.stats[:stats.numel()].copy_(stats, non_blocking=True)
         self.host.stats_ready.record(torch.cuda.current_stream(dev))
 
     def stage3(self):
-        if self.network_crop is None or self.K == 0:
+        if self.network_crop is None or self.K == 0 or not self.host_order:
             return
-        dev, H, W, B, K = self.dev, self.H, self.W, self.B, self.K
+        dev, H, W, K = self.dev, self.H, self.W, self.K
         self.host.stats_ready.synchronize()
         refined = _paste(self.labels_crop, self.table, self.table_host, self.host.stats, self.has_depth, K, H, W, dev,
                          plan_host=self.host.plan)
-        out = refined.view(1, H, W)
-        if B > 1:    # match_label_crop returns zeros_like(initial_masks) with only item 0 painted (:153,:176-177)
-            full = torch.zeros((B, H, W), dtype=refined.dtype, device=dev)
-            full[0] = out[0]
-            out = full
-        self.refined = out
-        self.labels_crop = self.image = self.depth = None      # release the big intermediates
+        self._set_refined(refined)
+
+    def redo_with_host_order(self):
+        """The device ordering flagged this frame (NaN keys, >= 64 ROIs): order on the host from the same crop labels."""
+        refined, _ = _match_host_order(self.labels_crop, self.mask_crop, self.depth_crop, self.table, self.K, self.H, self.W, self.dev)
+        self._set_refined(refined)
 
     def result_device(self):
         """(labels [B,H,W] int32, refined [B,H,W] int32 or None), on the device."""
@@ -399,11 +481,12 @@ class FrameGroupJob:
     set, and the crops of all N frames in one stage-2 forward (batch K_1 + ... + K_N).  Twice the pixels / Winograd
     tiles per launch is what the convolution kernels need to fill 256 CUs with full-height tiles.  Every
     frame keeps its own ROI table, RNG and output; label maps are bit-identical to one-frame-at-a-time processing (the
-    kernels' per-output summation order does not depend on the batch).  Same three stages as FrameJob."""
+    kernels' per-output summation order does not depend on the batch).  Same stages as FrameJob."""
 
-    def __init__(self, samples, network, network_crop, depth_threshold, rngs):
+    def __init__(self, samples, network, network_crop, depth_threshold, rngs, host_order=None):
         self.samples, self.network, self.network_crop = list(samples), network, network_crop
         self.depth_threshold, self.rngs = depth_threshold, list(rngs)
+        self.host_order = FORCE_HOST_ORDER if host_order is None else host_order
         self.N = len(self.samples)
         self.K = [0] * self.N
         self.refined = [None] * self.N
@@ -476,12 +559,20 @@ class FrameGroupJob:
             if self.K[f] == 0:
                 continue
             a, b = self.off[f], self.off[f + 1]
+            if not self.host_order:
+                refined, _ = _match_device(self.labels_crop[a:b], mask[a:b], dep[a:b] if dep is not None else None,
+                                           self.tables[f], self.K[f], H, W, dev)
+                self.refined[f] = refined.view(H, W)
+                continue
             stats = _match_stats(self.labels_crop[a:b], mask[a:b], dep[a:b] if dep is not None else None, self.K[f], dev)
             self.host.stats_all[f, :stats.numel()].copy_(stats, non_blocking=True)
-        self.host.stats_ready.record(torch.cuda.current_stream(dev))
+        if self.host_order:
+            self.host.stats_ready.record(torch.cuda.current_stream(dev))
+        else:
+            self.labels_crop = self.image = self.depth = None
 
     def stage3(self):
-        if self.network_crop is None or sum(self.K) == 0:
+        if self.network_crop is None or sum(self.K) == 0 or not self.host_order:
             return
         dev, H, W = self.dev, self.H, self.W
         self.host.stats_ready.synchronize()
@@ -495,13 +586,13 @@ class FrameGroupJob:
         self.labels_crop = self.image = self.depth = None
 
     def pending_event(self, state):
-        """The event of the device->host read the next stage waits for (state 1: ROI tables, 2: match statistics), or
-        None if that stage has nothing to wait for."""
+        """The event of the device->host read the next stage waits for (state 1: ROI tables; 2, host ordering only: match
+        statistics), or None if that stage has nothing to wait for."""
         if self.network_crop is None:
             return None
         if state == 1:
             return self.host.table_ready
-        return self.host.stats_ready if sum(self.K) > 0 else None
+        return self.host.stats_ready if (self.host_order and sum(self.K) > 0) else None
 
     def final_maps(self):
         """Per frame: the refined map if stage 2 produced one, else the stage-1 map ([H,W] int32, device)."""
@@ -521,19 +612,65 @@ def _cluster_fields(features, firsts):
     return labels
 
 
-def _run_frame(sample, network, network_crop, depth_threshold, return_device=False):
+def _run_frame_graphed(sample, network, network_crop, depth_threshold, checked):
+    """The frame as hipGraph replays (fcn/graph_replay.py) when the call qualifies — cfg.TEST.GRAPH_REPLAY, a single-image
+    sample, SEGNET networks, and not the first call of this (networks, size, configuration) combination — else None and
+    the caller runs the eager FrameJob.  Same label maps either way (tests/test_graph_replay_gpu.py)."""
+    from . import graph_replay as GR
+    if FORCE_HOST_ORDER or not getattr(cfg.TEST, "GRAPH_REPLAY", False) or "label" in sample:
+        return None
+    from ..networks.SEG import SEGNET
+    if not isinstance(network, SEGNET) or not (network_crop is None or isinstance(network_crop, SEGNET)):
+        return None
+    require_supported()
+    dev = _device()
+    if "image_u8" in sample:
+        from ..io import prepare_on_device
+        sample = dict(sample, **prepare_on_device(sample, dev))
+    image = sample["image_color"]
+    if image.dim() != 4 or image.shape[0] != 1:
+        return None
+    _, _, H, W = image.shape
+    has_depth = uses_depth()
+    thr = depth_threshold if has_depth else None
+    gf = GR.frame_for(network, network_crop, H, W, dev, thr)
+    if gf is None:
+        return None
+    image = image.to(dev, non_blocking=True).float()
+    depth = sample["depth"].to(dev, non_blocking=True).float() if has_depth else None
+    labels, refined, K, redo = gf.run(image, depth, None)
+    LAST_FRAME_STATS["rois"] = K
+    if checked:
+        _check_clustering(dev)              # synchronises
+        if K > 0 and gf.order_flagged():
+            refined = redo()
+    return labels, refined
+
+
+def _run_frame(sample, network, network_crop, depth_threshold, return_device=False, checked=None):
     """Per-frame body shared by test_sample (:247-261) and test_segnet (:288-321).
     depth_threshold None = no depth-coverage filter.  return_device=True keeps the int32 label
-    maps on the device ([B,H,W], [1,H,W] or None) for the frame-parallel runner."""
-    job = FrameJob(sample, network, network_crop, depth_threshold)
-    job.stage1()
-    job.stage2()
-    job.stage3()
-    LAST_FRAME_STATS["rois"] = job.K
-    labels, out_label_refined = job.result_device()
+    maps on the device ([B,H,W], [1,H,W] or None).  checked (default: not return_device): synchronise and check the
+    clustering status + the ordering flag before returning; the frame-parallel runner passes False and checks once per
+    block (_finish_block)."""
+    if checked is None:
+        checked = not return_device
+    graphed = _run_frame_graphed(sample, network, network_crop, depth_threshold, checked)
+    if graphed is not None:
+        labels, out_label_refined = graphed
+    else:
+        job = FrameJob(sample, network, network_crop, depth_threshold)
+        job.stage1()
+        job.stage2()
+        job.stage3()
+        LAST_FRAME_STATS["rois"] = job.K
+        if checked:
+            _check_clustering(job.dev)          # synchronises
+            if job.K > 0 and not job.host_order and _order_needs_host(job.dev):
+                job.redo_with_host_order()
+        labels, out_label_refined = job.result_device()
     if return_device:
         return labels, out_label_refined
-    _check_clustering(job.dev)
     out_label = labels.float().cpu()
     if out_label_refined is not None:
         out_label_refined = out_label_refined.float().cpu()
@@ -570,11 +707,10 @@ def test_segnet(test_loader, network, output_dir, network_crop):
     threshold = 0.5 if "ocid" in name else (0.8 if "osd" in name else None)      # :299-305
     for i, sample in enumerate(test_loader):
         end = time.time()
-        labels_dev, refined_dev = _run_frame(sample, network, network_crop, threshold, return_device=True)
+        labels_dev, refined_dev = _run_frame(sample, network, network_crop, threshold, return_device=True, checked=True)
         prediction_dev = labels_dev.reshape(labels_dev.shape[-2:]) if labels_dev.shape[0] == 1 else labels_dev[0]
         refined_2d = refined_dev[0] if refined_dev is not None else prediction_dev
         prediction = labels_dev.float().cpu().squeeze().numpy()
-        _check_clustering(labels_dev.device)
         prediction_refined = refined_dev.float().cpu().squeeze().numpy() if refined_dev is not None else prediction.copy()
         result = {"labels": prediction, "labels_refined": prediction_refined, "filename": sample.get("filename", "")}
         if "label" in sample:

@@ -80,6 +80,7 @@ class SEGNET(nn.Module):
                 _attach(self, f"{br}.resnet34_8s.{name}", t, is_buf)
         self._handle = None
         self._handle_device = None
+        self._native_gen = 0          # bumped whenever the native weight copy is rebuilt (captured hipGraphs bake its pointers)
         self.train(False)
 
     # -- native network management -----------------------------------------------------------
@@ -121,6 +122,7 @@ class SEGNET(nn.Module):
             _native.check(L.uoc_net_finalize(h), "uoc_net_finalize")
         self._handle = h
         self._handle_device = device
+        self._native_gen = getattr(self, "_native_gen", 0) + 1
 
     # -- forward ---------------------------------------------------------------------------------
     def forward(self, img, label=None, depth=None):
@@ -170,6 +172,7 @@ def _net_workspace(device, nbytes):
     key = _native.stream_key(device)      # one activation arena per stream (frames in flight do not share it)
     ws = _net_ws.get(key)
     if ws is None or ws.numel() < nbytes:
+        _native.retire(ws)          # a captured hipGraph may have baked the old arena's address
         ws = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=device)
         _net_ws[key] = ws
     return ws

@@ -75,7 +75,7 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     error = None
     if inflight is None:
         inflight = int(os.environ.get("UOC_FRAMES_IN_FLIGHT", "3"))
-    try:
+    def run_block():
         if (inflight > 1 or getattr(frame_fn, "frames_per_launch", 1) > 1) and device.type == "cuda" and hasattr(frame_fn, "make_job"):
             top = _run_block_pipelined(frame_fn, lo, hi, block, device, inflight)
         else:
@@ -89,6 +89,21 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
             frame_fn.finish(device)
         if hi > lo and int(top) > 255:       # one sync per block, after the last frame
             raise ValueError(f"label id {int(top)} does not fit the uint8 label-map block")
+
+    try:
+        from .fcn import test_dataset as TD
+        counted = len(getattr(frame_fn, "roi_counts", ()))
+        try:
+            run_block()
+        except TD.HostOrderNeeded:
+            # a frame had NaN ROI sort keys with >= 64 ROIs (the one ordering case uoc_roi_match leaves to Python's own
+            # sorted): the block runs again with the ordering on the host, same seeds -> same draws
+            del getattr(frame_fn, "roi_counts", [])[counted:]
+            was, TD.FORCE_HOST_ORDER = TD.FORCE_HOST_ORDER, True
+            try:
+                run_block()
+            finally:
+                TD.FORCE_HOST_ORDER = was
     except Exception as e:       # noqa: BLE001 - re-raised below, on every rank
         if not collective:
             raise
@@ -155,7 +170,8 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
     """Frames lo..hi-1 of this rank on `depth` streams, each stream working on one job (fcn.test_dataset.FrameGroupJob:
     `frames_per_launch` frames batched into one set of launches per stage).
 
-    A job has two points where the host needs a few bytes from the device (ROI counts; crop keep tables + ROI order).
+    A job has ONE point where the host needs a few bytes from the device (the ROI counts that size the stage-2 launches;
+    until round 5 also the crop keep tables for the ROI order, which uoc_roi_match now computes on the device).
     With one frame at a time the matrix pipes idle through those reads and through the latency-bound kernels around
     them (farthest-point sampling 2 x 0.5 ms, seed components, glue).  Here every job runs on its own stream and the
     host, a single thread, is event-driven: it queues the next stage of whichever job's read has landed and never waits
@@ -205,7 +221,8 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
             if state == 1:
                 job.stage2()
                 slots[slot][2] = 2
-                return True
+                if job.pending_event(2) is not None:      # host ordering only: the statistics are on their way to the host
+                    return True
             job.stage3()
             for i, m in zip(idx, job.final_maps()):       # int32 [H, W] (contiguous) -> the uint8 row of the block
                 with torch.cuda.device(device):
@@ -262,7 +279,7 @@ def two_stage_frame_fn(samples, network, network_crop, first_index: int = 0, fra
     Global frame i reads samples[(i - first_index) % len(samples)] (a rank passes the start of its block).
     frames_per_launch (default $UOC_FRAMES_PER_LAUNCH or 4): frames the pipelined runner batches into one launch set
     (fcn.test_dataset.FrameGroupJob)."""
-    from .fcn.test_dataset import _run_frame, _check_clustering, DEPTH_FILTER, LAST_FRAME_STATS, FrameGroupJob
+    from .fcn.test_dataset import _run_frame, _finish_block, DEPTH_FILTER, LAST_FRAME_STATS, FrameGroupJob
 
     def fn(i: int) -> torch.Tensor:
         out, refined = _run_frame(samples[(i - first_index) % len(samples)], network, network_crop, DEPTH_FILTER, return_device=True)
@@ -284,7 +301,7 @@ def two_stage_frame_fn(samples, network, network_crop, first_index: int = 0, fra
     fn.group_size = group_size
     fn.frames_per_launch = frames_per_launch if frames_per_launch is not None else int(os.environ.get("UOC_FRAMES_PER_LAUNCH", "4"))
     fn.roi_counts = []          # stage-1 ROIs per processed frame (the bench derives the algorithmic work from it)
-    # every frame checks the clustering status once after stage 1 (a sticky device flag, so a stage-2 failure
-    # surfaces at the next frame); fn.finish() is the check after the last frame
-    fn.finish = lambda dev: _check_clustering(dev)
+    # fn.finish() checks the sticky device flags once per block: the clustering status (uoc_ms_check) and the ordering flag
+    # of uoc_roi_match (HostOrderNeeded -> run_sharded re-runs the block with the ROI ordering on the host)
+    fn.finish = lambda dev: _finish_block(dev)
     return fn

@@ -26,6 +26,7 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
     key = _native.stream_key(device)      # one scratch buffer per stream (frames in flight do not share it)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
+        _native.retire(ws)          # a captured hipGraph may have baked the old buffer's address
         ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
         _ws_cache[key] = ws
     return ws
@@ -47,7 +48,13 @@ def _require_cosine(metric):
 
 
 def _first_indices(first_index, B: int, n: int) -> torch.Tensor:
-    """The B first-seed indices as an int32 host tensor, validated: the kernels read row X[first] directly."""
+    """The B first-seed indices as an int32 host tensor, validated: the kernels read row X[first] directly.
+    A device int32 tensor [B] passes through as it is (fcn/graph_replay.py: the indices live in a static buffer that is
+    refilled before every replay; the caller validated them)."""
+    if torch.is_tensor(first_index) and first_index.is_cuda:
+        if first_index.dtype != torch.int32 or first_index.numel() != B or not first_index.is_contiguous():
+            raise ValueError(f"first_index on the device must be a contiguous int32 tensor of {B} indices")
+        return first_index
     first = np.asarray(first_index, dtype=np.int64).reshape(-1)
     if first.shape[0] != B:
         raise ValueError(f"first_index: expected {B} indices, got {first.shape[0]}")
