@@ -409,7 +409,7 @@ def compact_line(full, full_path):
         if isinstance(v, list) and len(v) > 8:
             out["parity"][k] = {"frames": len(v), "sum": int(sum(v)), "max": int(max(v)), "first": v[:8]}
     lat = full.get("latency")
-    out["latency"] = _pick(lat, ("ms_per_frame", "frames_per_s", "graph_replay"))
+    out["latency"] = _pick(lat, ("ms_per_frame", "frames_per_s", "graph_replay_ms_per_frame"))
     sus = full.get("sustained")
     out["sustained_frames_per_s"] = sus["frames_per_s"] if sus else None
     out["pcie_inclusive_frames_per_s"] = full.get("pcie_inclusive_frames_per_s")
@@ -477,6 +477,7 @@ def main():
                     help="frames batched into one set of launches per stage (fcn.test_dataset.FrameGroupJob)")
     ap.add_argument("--skip-pcie", action="store_true", help="skip the PCIe-inclusive leg (profiling runs)")
     ap.add_argument("--skip-latency", action="store_true", help="skip the one-frame-at-a-time latency leg (profiling runs)")
+    ap.add_argument("--skip-graph-leg", action="store_true", help="skip the hipGraph-replay variant of the latency leg")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
@@ -638,10 +639,9 @@ def main():
     latency = None
     if solo and not args.skip_latency:
         # BASELINE configs[3] read literally ("batch=1"): ONE frame at a time on one stream, host waiting for each result
-        # (round 6: such calls replay hipGraphs — fcn/graph_replay.py, two graph launches and one 4-byte read per frame; the
-        # untimed pass below is the first use of every ROI count among these frames = its capture)
+        # (round 6: the ROI ordering runs on the device, so a frame has ONE mid-frame host wait — the ROI count — and the final read)
         nlat = min(hi - lo, 12)
-        for g in list(range(lo, lo + nlat)) + [lo]:
+        for g in range(lo, lo + min(nlat, 2)):
             np.random.seed(runner.frame_rng_seed(g))
             frame_fn(g).cpu()
         sync()
@@ -651,11 +651,9 @@ def main():
             frame_fn(g).to(torch.uint8).cpu()
         sync()
         el = time.perf_counter() - t1
-        from unseenobjectclustering_amd.fcn import graph_replay as GR
         latency = {"frames_per_launch": 1, "streams": 1, "frames": nlat, "ms_per_frame": round(1e3 * el / nlat, 3),
-                   "frames_per_s": round(nlat / el, 3),
-                   "graph_replay": bool(cfg.TEST.GRAPH_REPLAY) and any(v for v in GR._frames.values())}
-        del frame_fn.roi_counts[-(2 * nlat + 1):]
+                   "frames_per_s": round(nlat / el, 3)}
+        del frame_fn.roi_counts[-(nlat + min(nlat, 2)):]
 
     sustained = None
     if solo and args.sustained_seconds > 0:
@@ -773,6 +771,24 @@ def main():
             cpu = cpu_baseline_subprocess(min(args.cpu_frames, total), out_path)
             if os.path.exists(out_path):
                 parity = parity_report(maps.numpy(), out_path, network, network_crop, device)
+
+    if solo and latency is not None and not args.skip_graph_leg:
+        # the same leg as hipGraph replays (fcn/graph_replay.py: two graph launches and one 4-byte read per frame), bit-identical
+        # maps.  LAST GPU work of the process: captured graphs cost the multi-stream schedule ~5 % (measured)
+        cfg.TEST.GRAPH_REPLAY = True
+        nlat = latency["frames"]
+        for g in list(range(lo, lo + nlat)) * 2:        # first use of every ROI count (eager) + its capture
+            np.random.seed(runner.frame_rng_seed(g))
+            frame_fn(g).cpu()
+        sync()
+        t1 = time.perf_counter()
+        for g in range(lo, lo + nlat):
+            np.random.seed(runner.frame_rng_seed(g))
+            frame_fn(g).to(torch.uint8).cpu()
+        sync()
+        latency["graph_replay_ms_per_frame"] = round(1e3 * (time.perf_counter() - t1) / nlat, 3)
+        cfg.TEST.GRAPH_REPLAY = False
+        del frame_fn.roi_counts[-3 * nlat:]
 
     if rank == 0 and os.environ.get("UOC_BENCH_DUMP"):     # tests: the label-map block of the timed region
         np.save(os.environ["UOC_BENCH_DUMP"], maps.numpy())

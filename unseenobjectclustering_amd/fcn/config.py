@@ -10,6 +10,8 @@ asked for anything else.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -51,7 +53,10 @@ cfg.TRAIN.EMBEDDING_ALPHA = 0.02       # config.py:254 ; epsilon = 2*alpha (mean
 cfg.TEST = AttrDict()
 cfg.TEST.VISUALIZE = False             # config.py:319
 cfg.TEST.IMS_PER_BATCH = 1             # config.py:330
-cfg.TEST.GRAPH_REPLAY = True           # (no reference counterpart) one-frame-at-a-time calls replay hipGraphs: fcn/graph_replay.py
+# (no reference counterpart) one-frame-at-a-time calls replay hipGraphs (fcn/graph_replay.py).  OFF by default: bit-identical
+# to the eager path but measured no faster (7.78 vs 7.76 ms per frame, profiles/r06_latency.md — the frame is kernel-bound once
+# the ROI ordering runs on the device), and captured graphs in a process cost its multi-stream throughput schedule 5 %.
+cfg.TEST.GRAPH_REPLAY = os.environ.get("UOC_GRAPH_REPLAY", "0") == "1"
 cfg.TEST.ROS_CAMERA = "camera"         # config.py:327 ('D415' | 'Azure' | a kinect-style namespace)
 cfg.TEST.SCALES_BASE = (0.25, 0.5, 1.0, 2.0, 3.0)   # config.py:353 (every shipped yml sets (1.0,))
 cfg.TEST.CLASSES = (0, 1, 2, 3)        # config.py:346 (if emptied, tools/test_net.py:68-69 copies TRAIN.CLASSES)

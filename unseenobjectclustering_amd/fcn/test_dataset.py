@@ -359,7 +359,7 @@ def test_sample(sample, network, network_crop):
     return _run_frame(sample, network, network_crop, DEPTH_FILTER)
 
 
-FORCE_HOST_ORDER = False      # True: ROI ordering on the host (rounds 1-5; the fallback for NaN keys with >= 64 ROIs)
+FORCE_HOST_ORDER = os.environ.get("UOC_HOST_ORDER", "0") == "1"      # True: ROI ordering on the host (rounds 1-5; the fallback for NaN keys with >= 64 ROIs; A/B)
 
 
 class HostOrderNeeded(_native.NativeError):
@@ -566,9 +566,10 @@ class FrameGroupJob:
                 continue
             stats = _match_stats(self.labels_crop[a:b], mask[a:b], dep[a:b] if dep is not None else None, self.K[f], dev)
             self.host.stats_all[f, :stats.numel()].copy_(stats, non_blocking=True)
-        if self.host_order:
-            self.host.stats_ready.record(torch.cuda.current_stream(dev))
-        else:
+        # host ordering: the statistics are on their way to the host.  Device ordering: the same event marks "stage 2 has
+        # run" — the runner frees the slot only then (see pending_event)
+        self.host.stats_ready.record(torch.cuda.current_stream(dev))
+        if not self.host_order:
             self.labels_crop = self.image = self.depth = None
 
     def stage3(self):
@@ -586,13 +587,17 @@ class FrameGroupJob:
         self.labels_crop = self.image = self.depth = None
 
     def pending_event(self, state):
-        """The event of the device->host read the next stage waits for (state 1: ROI tables; 2, host ordering only: match
-        statistics), or None if that stage has nothing to wait for."""
+        """The event the next stage waits for (state 1: the ROI tables have landed on the host; state 2: stage 2 has run —
+        with host ordering that is the arrival of the match statistics), or None if there is nothing to wait for.
+        State 2 is a wait although the device ordering needs nothing from the device any more: a stream that is handed its
+        next job's stage 1 while this job's stage 2 is still queued puts that job's sampling kernel into the per-device event
+        chain (csrc/meanshift.hip) AHEAD of the other streams' stage-2 sampling kernels, which then wait behind this
+        stream's whole stage 2 — measured 168 -> 161 frames/s (same box, round 6)."""
         if self.network_crop is None:
             return None
         if state == 1:
             return self.host.table_ready
-        return self.host.stats_ready if (self.host_order and sum(self.K) > 0) else None
+        return self.host.stats_ready if sum(self.K) > 0 else None
 
     def final_maps(self):
         """Per frame: the refined map if stage 2 produced one, else the stage-1 map ([H,W] int32, device)."""

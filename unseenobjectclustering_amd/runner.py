@@ -215,13 +215,16 @@ def _run_block_pipelined(frame_fn, lo: int, hi: int, block: torch.Tensor, device
         for it).  Returns True if something was issued."""
         idx, job, state = slots[slot]
         ev = job.pending_event(state)
-        if ev is not None and not block_host and not ev.query():
-            return False
+        if ev is not None:
+            if block_host:
+                ev.synchronize()
+            elif not ev.query():
+                return False
         with torch.cuda.stream(streams[slot]):
             if state == 1:
                 job.stage2()
                 slots[slot][2] = 2
-                if job.pending_event(2) is not None:      # host ordering only: the statistics are on their way to the host
+                if job.pending_event(2) is not None:      # the slot is freed when stage 2 has run (FrameGroupJob.pending_event)
                     return True
             job.stage3()
             for i, m in zip(idx, job.final_maps()):       # int32 [H, W] (contiguous) -> the uint8 row of the block
