@@ -435,8 +435,66 @@ def compact_line(full, full_path):
     return out
 
 
+METRIC = "frames/sec at 640x480 RGB-D, two-stage clustering"
+# where a run currently is (the `stage` of an error record) and whether this process already wrote its JSON line
+STATE = {"stage": "init", "emitted": False, "json_fd": None, "rank": 0, "world": 1, "t0": time.time()}
+
+
+def error_line(stage, err, n_gpus, **extra):
+    """The ONE JSON line of a failed run: the contract's metric with value null, what failed and where."""
+    rec = {"metric": METRIC, "value": None, "unit": "frames/s", "n_gpus": n_gpus, "error": str(err)[:600], "stage": stage,
+           "higher_is_better": True, "elapsed_s": round(time.time() - STATE["t0"], 1)}
+    rec.update(extra)
+    return json.dumps(rec, separators=(",", ":"))
+
+
+def _nccl_log_tail(limit=1500):
+    """Tail of the NCCL_DEBUG=WARN side files of this run (multi-rank runs point NCCL_DEBUG_FILE into gpurun_out/)."""
+    import glob
+    pat = os.environ.get("UOC_NCCL_LOG_GLOB")
+    if not pat:
+        return None
+    out = []
+    for p in sorted(glob.glob(pat))[:16]:
+        try:
+            txt = open(p, errors="replace").read().strip()
+        except OSError:
+            continue
+        if txt:
+            out.append(f"{os.path.basename(p)}: {txt[-300:]}")
+    return "\n".join(out)[-limit:] or None
+
+
+def emit_error(stage, err):
+    """Rank 0 (or a single process) writes the error record once, to the duplicate of the original stdout."""
+    if STATE["emitted"] or STATE["rank"] != 0:
+        return
+    STATE["emitted"] = True
+    line = error_line(stage, err, STATE["world"], nccl_log=_nccl_log_tail())
+    fd = STATE["json_fd"] if STATE["json_fd"] is not None else 1
+    try:
+        os.write(fd, (line + "\n").encode())
+    except OSError:
+        pass
+
+
+def _stage():
+    """The stage an error record names: inside the timed region, 'gather' once this rank's frame block is done."""
+    st, tm = STATE["stage"], STATE.get("timing") or {}
+    return "gather" if st == "timed" and "compute_s" in tm and "gather_s" not in tm else st
+
+
+def _on_sigterm(signum, frame):
+    # torch.distributed.run terminates the surviving ranks when one rank dies: rank 0 still owes the driver its record
+    emit_error(_stage(), f"terminated by signal {signum} (the launcher stops all ranks when one rank fails); "
+                         f"this rank was in stage '{_stage()}'")
+    os._exit(143)
+
+
 def relaunch_under_torchrun(n):
-    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one process per GPU)."""
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks ourselves (one process per GPU) and make sure ONE
+    JSON line comes out whatever happens to them: rank 0's line is passed through; if the ranks exit non-zero (or exceed
+    $UOC_BENCH_TIMEOUT seconds, default 3600) without one, the launcher writes the error record itself."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -446,7 +504,72 @@ def relaunch_under_torchrun(n):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
-    return subprocess.call(cmd, env=env)
+    limit = float(os.environ.get("UOC_BENCH_TIMEOUT", "3600"))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, start_new_session=True)
+    seen = []
+
+    def pump():
+        for raw in proc.stdout:
+            txt = raw.decode(errors="replace")
+            if txt.lstrip().startswith("{") and '"metric"' in txt:
+                seen.append(txt)
+            sys.stdout.write(txt)
+            sys.stdout.flush()
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    try:
+        rc = proc.wait(timeout=limit)
+        why = f"the ranks exited with code {rc}"
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGTERM)
+        try:
+            proc.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait()
+        rc, why = 124, f"no result after {limit:.0f} s: the ranks were stopped"
+    t.join(timeout=5)
+    if rc != 0 and not seen:
+        print(error_line("launch", why + " and rank 0 left no record", n, nccl_log=_nccl_log_tail()), flush=True)
+    return rc if rc != 0 or seen else 1
+
+
+def numa_pin(device_index, local_rank, local_world):
+    """Pins this rank to the cores of its GPU's NUMA node (its share of them when several ranks sit on one node), so that the
+    event-driven host loop, torch's copy threads and the frame-synthesis workers of a rank stay next to its GPU and the ranks
+    do not wander over each other's cores.  Best effort: returns {'numa_node', 'cpus'} or None (no sysfs entry, no rights)."""
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = f"{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = []
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += list(range(int(a), int(b or a) + 1))
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        # ranks whose GPUs share this node split its cores evenly (the same computation on every rank)
+        mates = []
+        for i in range(local_world):
+            try:
+                p = torch.cuda.get_device_properties(i)
+                n_i = int(open(f"/sys/bus/pci/devices/{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0/numa_node").read())
+            except Exception:      # noqa: BLE001
+                n_i = -1
+            if n_i == node:
+                mates.append(i)
+        if device_index in mates and len(mates) > 1:
+            share = max(2, len(allowed) // len(mates))
+            k = mates.index(device_index)
+            allowed = allowed[k * share:(k + 1) * share] or allowed
+        if len(allowed) < 2:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return {"numa_node": node, "cpus": len(allowed)}
+    except Exception:          # noqa: BLE001 - best effort
+        return None
 
 
 def stub_frame_fn(h, w):
@@ -461,7 +584,57 @@ def stub_frame_fn(h, w):
     return fn
 
 
+def _fault(stage, rank, args):
+    """Test hook of the CPU launcher tests (honoured only with --stub): UOC_BENCH_FAULT="<rank>:<stage>:<kind>" makes that rank
+    raise / hang / die (SIGKILL) when it reaches that stage."""
+    spec = os.environ.get("UOC_BENCH_FAULT", "")
+    if not spec or not args.stub:
+        return
+    r, st, kind = spec.split(":")
+    if int(r) != rank or st != stage:
+        return
+    if kind == "raise":
+        raise RuntimeError(f"injected fault: rank {rank} raises in stage {stage}")
+    if kind == "hang":
+        time.sleep(10_000)
+    if kind == "exit":
+        os.kill(os.getpid(), 9)
+
+
+def _watch_sigterm():
+    """SIGTERM must produce the error record even while the main thread is blocked inside a collective / the rendezvous
+    (a Python-level signal handler only runs between bytecodes): the C-level handler writes to a wake-up pipe and a daemon
+    thread reading it emits the record and leaves."""
+    import signal
+    r, w = os.pipe()
+    os.set_blocking(w, False)
+    signal.set_wakeup_fd(w, warn_on_full_buffer=False)
+    signal.signal(signal.SIGTERM, lambda *a: None)
+
+    def waiter():
+        os.read(r, 1)
+        _on_sigterm(15, None)
+    threading.Thread(target=waiter, daemon=True).start()
+
+
 def main():
+    try:
+        return _main()
+    except BaseException as e:      # noqa: BLE001 - every failure must leave the one JSON line behind
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        import traceback
+        traceback.print_exc()
+        emit_error(_stage(), f"{type(e).__name__}: {e}")
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:           # noqa: BLE001
+            pass
+        return 1
+
+
+def _main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64, help="frames per GPU (weak scaling)")
@@ -481,6 +654,8 @@ def main():
     ap.add_argument("--cpu-baseline-only", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("UOC_BENCH_DIST_TIMEOUT", "300")),
+                    help="seconds the rendezvous and every collective may take before the run fails with an error record")
     args = ap.parse_args()
     if args.cpu_baseline_only > 0:
         print(json.dumps(cpu_baseline(args.cpu_baseline_only, args.cpu_out)), flush=True)
@@ -498,6 +673,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    STATE.update(json_fd=json_fd, rank=rank, world=world, stage="init")
+    if rank == 0 and world > 1:
+        _watch_sigterm()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     stub = args.stub
@@ -518,11 +696,24 @@ def main():
         torch.cuda.set_device(dev_index)
         device, backend, h, w = torch.device("cuda", dev_index), os.environ.get("UOC_BENCH_BACKEND", "nccl"), H, W
     use_dist = world > 1 or os.environ.get("UOC_BENCH_FORCE_DIST") == "1"   # FORCE: exercise the RCCL path on 1 GPU
+    pinned = None
+    if not stub and world > 1 and os.environ.get("UOC_BENCH_PIN", "1") != "0" and os.environ.get("UOC_BENCH_ONE_DEVICE") != "1":
+        pinned = numa_pin(dev_index, local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if use_dist:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl" and world > 1:
+            # RCCL's warnings of a failing first multi-GPU run go to side files next to the full record
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            os.environ.setdefault("NCCL_DEBUG", "WARN")
+            os.environ.setdefault("NCCL_DEBUG_FILE", os.path.join(ROOT, "gpurun_out", f"nccl_{os.environ['MASTER_PORT']}_%h_%p.log"))
+            os.environ["UOC_NCCL_LOG_GLOB"] = os.path.join(ROOT, "gpurun_out", f"nccl_{os.environ['MASTER_PORT']}_*.log")
+        _fault("init", rank, args)
         kw = {} if stub or backend != "nccl" else {"device_id": device}
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.dist_timeout), **kw)
+    STATE["stage"] = "setup"
+    _fault("setup", rank, args)
 
     from unseenobjectclustering_amd import runner
     sync = (lambda: None) if stub else torch.cuda.synchronize
@@ -552,7 +743,7 @@ def main():
         frame_fn = runner.two_stage_frame_fn(samples, network, network_crop, first_index=lo,     # global index -> resident sample
                                              frames_per_launch=args.frames_per_launch)
 
-    rank_timing = {}
+    rank_timing = STATE["timing"] = {}
 
     def run(nframes_total, gather):
         maps = runner.run_sharded(nframes_total, frame_fn, h, w, device, rank, world, gather, force_collective=use_dist,
@@ -589,7 +780,9 @@ def main():
     sync()
     if use_dist:
         dist.barrier()
+    STATE["stage"] = "timed"
     t0 = time.perf_counter()
+    _fault("timed", rank, args)
     maps = run(total, use_dist)
     sync()
     if use_dist:
@@ -603,6 +796,8 @@ def main():
     print(f"[bench] rank {rank}: timed region {dt:.3f}s (this rank: setup {rank_timing['setup_s']:.1f}s, compute "
           f"{rank_timing.get('compute_s', 0.0):.3f}s for {rank_timing.get('frames', 0)} frames, gather "
           f"{rank_timing.get('gather_s', 0.0):.3f}s)", file=sys.stderr, flush=True)
+    if pinned is not None:
+        rank_timing.update(pinned)          # numa_node / cpus this rank is pinned to
     per_rank = [rank_timing]
     if use_dist:
         per_rank = [None] * world
@@ -610,7 +805,9 @@ def main():
     objects = float(np.mean([int(m.max()) for m in maps[:total]]))
     counts = frame_fn.roi_counts[-(hi - lo):] if frame_fn.roi_counts else []
     rois = float(np.mean(counts)) if counts else 0.0
+    STATE["stage"] = "report"
     solo = rank == 0 and world == 1 and not stub
+    lead = rank == 0 and not stub       # round 6: rank 0 also fills roofline / cpu_baseline / parity of a multi-GPU run (after the gather)
 
     pcie = None
     if solo and not args.skip_pcie:
@@ -673,7 +870,7 @@ def main():
 
     # ---- profiled pass (HIP events around every launch; separate from the timed region) ----
     roof, kernels = None, []
-    if solo and args.profile_steps > 0:
+    if lead and args.profile_steps > 0:
         # the launch shapes of the timed region (launch sets of --frames-per-launch frames), but one launch set at a time
         # on one stream: the HIP events around a launch then time that kernel alone
         nprof = min(hi - lo, args.profile_steps * max(1, args.frames_per_launch))
@@ -765,7 +962,7 @@ def main():
         roof["gpu_time_share"] = round(dom["total_ms"] / tot, 4)
 
     cpu = parity = None
-    if solo and args.cpu_frames > 0:
+    if lead and args.cpu_frames > 0:
         with tempfile.TemporaryDirectory() as td:
             out_path = os.path.join(td, "cpu_maps.npz")
             cpu = cpu_baseline_subprocess(min(args.cpu_frames, total), out_path)
@@ -800,7 +997,7 @@ def main():
             workload += (f"; configs[4]: {total} frames sharded over {world} GPU(s) in contiguous blocks + "
                          f"RCCL all_gather of the uint8 label maps" if use_dist else f"; {total} frames on one GPU")
         line = {
-            "metric": "frames/sec at 640x480 RGB-D, two-stage clustering",
+            "metric": METRIC,
             "value": round(total / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / K, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (stub frame function, CPU plumbing test)" if stub else ""),
@@ -812,8 +1009,8 @@ def main():
             "per_rank": [{k: round(v, 4) if isinstance(v, float) else v for k, v in (r or {}).items()} for r in per_rank],
             "pcie_inclusive_frames_per_s": pcie, "latency": latency, "sustained": sustained,
             "roofline": roof, "frame_roofline": frame_roofline(rois, dt / K) if not stub else None,
-            "cpu_baseline": cpu, "parity": parity, "kernels": kernels, "conv_by_shape": by_shape if solo and args.profile_steps > 0 else None,
-            "clustering_by_shape": clustering_by_shape if solo and args.profile_steps > 0 else None,
+            "cpu_baseline": cpu, "parity": parity, "kernels": kernels, "conv_by_shape": by_shape if lead and args.profile_steps > 0 else None,
+            "clustering_by_shape": clustering_by_shape if lead and args.profile_steps > 0 else None,
         }
     else:
         line = None

@@ -97,3 +97,45 @@ def test_compact_line_never_exceeds_the_cap_whatever_the_record_holds():
     assert len(json.dumps(bench.compact_line(full, "p"), separators=(",", ":"))) <= bench.MAX_LINE_BYTES
     fr = bench.frame_roofline(7.1, 5.97e-3)
     assert fr["mfma_frac"] < 1.0 < fr["algorithmic_mfma_frac"] and abs(fr["executed_gflop"] - (fr["algorithmic_gflop"] - 0.75 * (416.2 + 68.0 * 7.1))) < 0.2
+
+
+def _run_fault(fault, *flags, launcher="self", timeout=150):
+    """bench.py --stub with one rank misbehaving (UOC_BENCH_FAULT, honoured only with --stub).  launcher 'self': bench.py spawns
+    its ranks; 'torchrun': the driver's form (python -m torch.distributed.run ... bench.py --gpus N ...)."""
+    import socket
+    env = dict(os.environ, UOC_BENCH_FAULT=fault, UOC_BENCH_TIMEOUT="90")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    base = [os.path.join(ROOT, "bench.py"), "--stub", "--gpus", "2", "--steps", "3", "--warmup", "1", "--dist-timeout", "12", *flags]
+    if launcher == "torchrun":
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + base
+    else:
+        cmd = [sys.executable] + base
+    import time
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    took = time.time() - t0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    return r, lines, took
+
+
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+@pytest.mark.parametrize("fault,stages", [("1:setup:raise", ("setup", "timed", "gather")), ("1:init:hang", ("init",)),
+                                           ("1:timed:exit", ("timed", "gather", "setup")), ("0:setup:raise", ("setup",))])
+def test_a_failing_rank_leaves_one_error_record(fault, stages, launcher):
+    """the first multi-GPU run must not be able to fail silently.  A rank that raises during set-up, a
+    rank that never joins the rendezvous, a rank that dies inside the timed region — and rank 0 itself raising — each end
+    in a non-zero exit code and exactly ONE JSON line {"metric", "value": null, "error", "stage", "n_gpus"} within a bounded
+    time, under bench.py's own launcher and in the driver's torch.distributed.run form."""
+    r, lines, took = _run_fault(fault, launcher=launcher)
+    assert r.returncode != 0
+    assert len(lines) == 1, (r.stdout[-1500:], r.stderr[-1500:])
+    rec = json.loads(lines[0])
+    assert rec["value"] is None and rec["n_gpus"] == 2 and rec["metric"].startswith("frames/sec")
+    assert rec["error"] and rec["stage"] in stages + ("launch",), rec
+    assert took < 120, f"the error record took {took:.0f} s"

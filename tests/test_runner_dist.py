@@ -53,16 +53,23 @@ def test_two_rank_gather_equals_single_process(tmp_path, F):
         assert got.shape == (F, 6, 8) and torch.equal(got, single)
 
 
-def _mismatch_worker(rank, world, port, out_dir):
+def _mismatch_worker(rank, world, port, out_dir, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["UOC_TEST_FINGERPRINT"] = str(1000 + (1 if rank == 1 else 0))      # rank 1 "runs another library configuration"
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode == "mismatch":          # rank 1 "runs another library configuration"
+        runner.config_fingerprint = lambda: 1000 + (1 if rank == 1 else 0)
+    else:                           # rank 1's library is missing / too old to have a fingerprint
+        def broken():
+            if rank == 1:
+                raise AttributeError("undefined symbol: uoc_config_fingerprint")
+            return 1000
+        runner.config_fingerprint = broken
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=__import__("datetime").timedelta(seconds=60))
     try:
         runner.run_sharded(4, _frame, 6, 8, torch.device("cpu"), rank, world)
         msg = "no error"
-    except RuntimeError as e:
-        msg = str(e)
+    except (RuntimeError, AttributeError) as e:
+        msg = f"{type(e).__name__}: {e}"
     open(os.path.join(out_dir, f"r{rank}.txt"), "w").write(msg)
     dist.barrier()
     dist.destroy_process_group()
@@ -75,9 +82,25 @@ def test_ranks_with_different_library_configurations_fail_before_the_gather(tmp_
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_mismatch_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_mismatch_worker, args=(2, port, str(tmp_path), "mismatch"), nprocs=2, join=True)
     for r in range(2):
         assert "different libuoc_hip configurations" in open(os.path.join(str(tmp_path), f"r{r}.txt")).read()
+
+
+def test_a_rank_without_a_fingerprint_fails_on_every_rank_instead_of_hanging(tmp_path):
+    """config_fingerprint() raising on one rank (missing .so, a library that predates the symbol) used to
+    leave the other ranks waiting in the all-reduce until the process-group timeout.  The rank now joins the all-reduce
+    with an error flag: it re-raises its own error, the other rank raises 'another rank failed' — at once."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import time
+    t0 = time.time()
+    mp.spawn(_mismatch_worker, args=(2, port, str(tmp_path), "broken"), nprocs=2, join=True)
+    assert time.time() - t0 < 45
+    assert "another rank failed" in open(os.path.join(str(tmp_path), "r0.txt")).read()
+    assert "uoc_config_fingerprint" in open(os.path.join(str(tmp_path), "r1.txt")).read()
 
 
 def test_the_fingerprint_is_the_library_s():

@@ -578,6 +578,8 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
   if (p.stem) {
     UOC_REQUIRE(p.Cin == 4 && p.KH == 7 && p.KW == 7 && p.stride == 2 && p.pad == 3 && p.dil == 1 && p.Cout == 64,
                 "conv: stem path is 7x7 s2 p3, NHWC4 -> 64 only");
+    UOC_REQUIRE((size_t)p.B * p.H * p.W * p.Cin * 4 + (size_t)(p.pad * p.W + p.pad) * p.Cin * 4 < (1ull << 31),
+                "conv: the stem's input exceeds the 2 GB a 32-bit buffer offset addresses");
     return launch_glds<160, 64, 2, 4, true>(p, st, KC_CONV_STEM);
   }
   UOC_REQUIRE(p.Cin % BK == 0, "conv: Cin=%d must be a multiple of %d", p.Cin, BK);
@@ -599,6 +601,9 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
         if (p.res) q.res = p.res + (size_t)g * p.Ho * p.Wo * p.Cout;
         q.w = p.w + (size_t)g * p.KH * p.KW * p.Cout * p.Cin;
         if (p.bias) q.bias = p.bias + (size_t)g * p.Cout;
+        // the REAL limit of the 32-bit buffer offset, whatever the test limit above says
+        UOC_REQUIRE((size_t)q.B * q.H * q.W * q.Cin * 4 + halo < (1ull << 31),
+                    "conv: one image's input exceeds the 2 GB a 32-bit buffer offset addresses");
         const Choice ch1 = choose(q, st, use_glds);
         if (ch1.cfg < 0) {
           set_error("conv: no tile configuration for Cout=%d", p.Cout);
@@ -625,6 +630,8 @@ int launch_conv(const ConvParams &p, hipStream_t st) {
       }
     return UOC_OK;
   }
+  UOC_REQUIRE((size_t)p.B * p.H * p.W * p.Cin * 4 + halo < (1ull << 31),
+              "conv: a group's input exceeds the 2 GB a 32-bit buffer offset addresses");
   const Choice ch = choose(p, st, use_glds);
   if (ch.cfg < 0) {
     set_error("conv: no tile configuration for Cout=%d", p.Cout);

@@ -28,10 +28,8 @@ def shard_range(num_frames: int, rank: int, world: int):
 
 
 def config_fingerprint() -> int:
-    """63 bits of uoc_config_fingerprint() (what could make two ranks compute different bits); $UOC_TEST_FINGERPRINT
-    overrides it in the CPU tests of the mismatch path."""
-    if os.environ.get("UOC_TEST_FINGERPRINT"):
-        return int(os.environ["UOC_TEST_FINGERPRINT"])
+    """63 bits of uoc_config_fingerprint() (what could make two ranks compute different bits).  Tests of the mismatch path
+    replace this function (monkeypatch); nothing in the environment overrides it."""
     from . import _native
     return _native.config_fingerprint() & 0x7FFFFFFFFFFFFFFF
 
@@ -124,7 +122,14 @@ def run_sharded(num_frames: int, frame_fn: Callable[[int], torch.Tensor], height
     # one MAX all-reduce carries the error flag AND the configuration fingerprint (library version / development build and
     # its rounding-affecting knobs) as (fp, -fp): max(fp) != -max(-fp) means two ranks would not compute the same bits for
     # the same frame — sharding independence broken silently — so every rank fails before the gather
-    fp = config_fingerprint()
+    # (a rank whose library is missing or too old to HAVE a fingerprint must still join the all-reduce: it reports an error
+    # and fingerprint 0 instead of raising in front of a collective the other ranks are already waiting in)
+    try:
+        fp = config_fingerprint()
+    except Exception as e:       # noqa: BLE001
+        fp = 0
+        if error is None:
+            error = e
     flag = torch.tensor([1 if error is not None else 0, fp, -fp], dtype=torch.int64, device=coll_dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MAX)
     flag = flag.tolist()
