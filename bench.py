@@ -393,7 +393,7 @@ def compact_line(full, full_path):
                                 "scaling", "vs_baseline", "dtype", "data")}
     out["config"] = full["config"]
     roof = full.get("roofline")
-    out["roofline"] = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "avg_launch_us",
+    out["roofline"] = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes", "avg_launch_us",
                                    "gpu_time_share", "algorithmic_tflops", "matrix_pipe_tflops", "matrix_pipe_frac"))
     cpu = full.get("cpu_baseline")
     out["cpu_baseline"] = _pick(cpu, ("value", "unit", "cores", "host_cores", "cpu_model", "kind", "sample"))
@@ -417,11 +417,13 @@ def compact_line(full, full_path):
     out["frame_roofline"] = _pick(fr, ("rois_per_frame", "hbm_frac", "mfma_frac", "algorithmic_mfma_frac"))
     out["per_rank"] = [_pick(r, ("frames", "compute_s", "gather_s", "host_cpu_s")) for r in (full.get("per_rank") or [])][:8]
     out["kernel_time_share"] = {k["kernel"]: k["gpu_time_share"] for k in (full.get("kernels") or [])[:6]}
+    if full.get("kernels_pipe"):       # the same shares inside the shipped multi-stream schedule (transforms weigh more there)
+        out["kernel_time_share_pipe"] = {k["kernel"]: k["gpu_time_share"] for k in full["kernels_pipe"][:6]}
     out["full"] = full_path
     size = lambda: len(json.dumps(out, separators=(",", ":")))
     # never again: drop / shorten the optional parts, most expendable first, RE-MEASURING after each step, rather than lose
     # the record to the driver's output tail
-    steps = [lambda: out.pop("kernel_time_share", None), lambda: out.pop("per_rank", None), lambda: out.pop("frame_roofline", None),
+    steps = [lambda: out.pop("kernel_time_share_pipe", None), lambda: out.pop("kernel_time_share", None), lambda: out.pop("per_rank", None), lambda: out.pop("frame_roofline", None),
              lambda: out.__setitem__("config", _pick(out.get("config"), ("workload", "total_frames", "frames_per_gpu", "streams_per_gpu",
                                                                          "frames_per_launch")) or {}),
              lambda: out["config"].__setitem__("workload", str(out["config"].get("workload", ""))[:160]),
@@ -826,7 +828,9 @@ def _main():
             d["image_u8"], d["depth_u16"] = d["image_u8"].pin_memory(), d["depth_u16"].pin_memory()
             hs.append(d)
         fn2 = runner.two_stage_frame_fn(hs, network, network_crop, frames_per_launch=args.frames_per_launch)
-        runner.run_sharded(min(total, 2 * args.frames_per_launch), fn2, h, w, device, 0, 1, False, inflight=args.inflight)   # untimed: first use
+        # untimed: the first use of the raw-sample path on EVERY stream (allocator pools of the uint8 / uint16 staging tensors, the
+        # preparation kernel), two launch sets per stream like the main leg's warm-up
+        runner.run_sharded(min(total, 2 * args.inflight * args.frames_per_launch), fn2, h, w, device, 0, 1, False, inflight=args.inflight)
         sync()
         t1 = time.perf_counter()
         runner.run_sharded(total, fn2, h, w, device, 0, 1, False, inflight=args.inflight).cpu()
@@ -960,6 +964,27 @@ def _main():
 
     if roof is not None:
         roof["gpu_time_share"] = round(dom["total_ms"] / tot, 4)
+        if roof.get("traffic") is not None:
+            # not measured in THIS run: the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 corrections)
+            # of scripts/profile_round.sh, committed as profiles/traffic.json next to their tables (profiles/r0N_pmc_traffic.md)
+            roof["traffic_source"] = "profiles/traffic.json"
+
+    # ---- the same HIP-event timing inside the SHIPPED schedule (streams x launch sets): a kernel's duration next to the other
+    # streams' kernels.  The bandwidth-bound Winograd transforms take 2-3x their solo time there, so their share of the
+    # frame is larger than the solo table says.
+    kernels_pipe = None
+    if lead and args.profile_steps > 0 and args.inflight > 1:
+        npipe = min(hi - lo, 2 * args.inflight * max(1, args.frames_per_launch))
+        _native.prof_enable(True)
+        runner.run_sharded(npipe, frame_fn, h, w, device, 0, 1, False, inflight=args.inflight)
+        sync()
+        rep2 = _native.prof_report()
+        _native.prof_enable(False)
+        del frame_fn.roi_counts[-npipe:]
+        tot2 = sum(r["total_ms"] for r in rep2) or 1.0
+        kernels_pipe = [{"kernel": r["kernel"], "avg_us": round(1e3 * r["total_ms"] / r["launches"], 2),
+                         "gpu_time_share": round(r["total_ms"] / tot2, 4), "ms_per_frame": round(r["total_ms"] / npipe, 4)}
+                        for r in sorted(rep2, key=lambda r: -r["total_ms"])]
 
     cpu = parity = None
     if lead and args.cpu_frames > 0:
@@ -1009,7 +1034,7 @@ def _main():
             "per_rank": [{k: round(v, 4) if isinstance(v, float) else v for k, v in (r or {}).items()} for r in per_rank],
             "pcie_inclusive_frames_per_s": pcie, "latency": latency, "sustained": sustained,
             "roofline": roof, "frame_roofline": frame_roofline(rois, dt / K) if not stub else None,
-            "cpu_baseline": cpu, "parity": parity, "kernels": kernels, "conv_by_shape": by_shape if lead and args.profile_steps > 0 else None,
+            "cpu_baseline": cpu, "parity": parity, "kernels": kernels, "kernels_pipe": kernels_pipe, "conv_by_shape": by_shape if lead and args.profile_steps > 0 else None,
             "clustering_by_shape": clustering_by_shape if lead and args.profile_steps > 0 else None,
         }
     else:

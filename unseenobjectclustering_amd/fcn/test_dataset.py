@@ -498,16 +498,28 @@ class FrameGroupJob:
         # non_blocking is a no-op for pageable host memory (the runtime stages it synchronously) and asynchronous for
         # pinned memory; asking the tensor (`is_pinned()`) costs a driver query per call, so just always pass it
         pin = lambda t: t.to(dev, non_blocking=True)
-        images, depths = [], []
-        for sm in self.samples:
-            if "image_u8" in sm:
-                from ..io import prepare_on_device
-                sm = dict(sm, **prepare_on_device(sm, dev))
-            images.append(pin(sm["image_color"]).float())
-            if uses_depth():
-                depths.append(pin(sm["depth"]).float())
-        self.image = image = (torch.cat(images) if N > 1 else images[0]).contiguous()
-        self.depth = depth = ((torch.cat(depths) if N > 1 else depths[0]).contiguous()) if depths else None
+        if all("image_u8" in sm for sm in self.samples) and len({tuple(sm["depth_u16"].shape) for sm in self.samples}) == 1:
+            # raw samples (uint8 BGR + uint16 depth): asynchronous uploads, prepared on the device straight into the launch
+            # set's batched inputs
+            from ..io import prepare_on_device
+            Hs, Ws = self.samples[0]["depth_u16"].shape
+            image = torch.empty((N, 3, Hs, Ws), dtype=torch.float32, device=dev)
+            xyz = torch.empty((N, 3, Hs, Ws), dtype=torch.float32, device=dev)
+            for f, sm in enumerate(self.samples):
+                prepare_on_device(sm, dev, out=(image[f], xyz[f]))
+            self.image = image
+            self.depth = depth = xyz if uses_depth() else None
+        else:
+            images, depths = [], []
+            for sm in self.samples:
+                if "image_u8" in sm:
+                    from ..io import prepare_on_device
+                    sm = dict(sm, **prepare_on_device(sm, dev))
+                images.append(pin(sm["image_color"]).float())
+                if uses_depth():
+                    depths.append(pin(sm["depth"]).float())
+            self.image = image = (torch.cat(images) if N > 1 else images[0]).contiguous()
+            self.depth = depth = ((torch.cat(depths) if N > 1 else depths[0]).contiguous()) if depths else None
         thr = self.depth_threshold if depth is not None else None
         assert image.shape[0] == N, "FrameGroupJob takes single-image samples"
         _, _, H, W = image.shape

@@ -67,17 +67,25 @@ def make_sample_raw(im_bgr_u8, depth_u16, camera_params):
             "camera": dict(camera_params)}
 
 
-def prepare_on_device(sample, device):
+def prepare_on_device(sample, device, out=None):
     """image_u8 [H,W,3] uint8 + depth_u16 [H,W] (int16 view of uint16) -> float 'image_color' / 'depth'
-    [1,3,H,W] on `device`, bit-identical to make_sample()."""
+    [1,3,H,W] on `device`, bit-identical to make_sample().  out = (image [3,H,W], xyz [3,H,W]) contiguous float32 device
+    tensors to write into (a launch set's batched input, so that N frames need no torch.cat)."""
     from . import _native
-    bgr = sample["image_u8"].to(device).contiguous()
-    dep = sample["depth_u16"].to(device).contiguous()
+    # non_blocking: asynchronous for pinned host buffers (a capture pipeline's; the caller must not rewrite them before the
+    # frame is done), a plain synchronous copy for pageable ones.  Without it every upload also waits for the stream to drain —
+    # a host stall per frame that the event-driven runner cannot hide (round 6: the PCIe-inclusive leg's 9 % gap)
+    bgr = sample["image_u8"].to(device, non_blocking=True).contiguous()
+    dep = sample["depth_u16"].to(device, non_blocking=True).contiguous()
     H, W = dep.shape
     cam = sample["camera"]
     mean = (cfg.PIXEL_MEANS.reshape(-1) / 255.0).astype(np.float32)
-    image = torch.empty((1, 3, H, W), dtype=torch.float32, device=device)
-    xyz = torch.empty((1, 3, H, W), dtype=torch.float32, device=device)
+    if out is not None:
+        image, xyz = out
+        assert image.shape[-3:] == (3, H, W) and xyz.shape[-3:] == (3, H, W) and image.is_contiguous() and xyz.is_contiguous()
+    else:
+        image = torch.empty((1, 3, H, W), dtype=torch.float32, device=device)
+        xyz = torch.empty((1, 3, H, W), dtype=torch.float32, device=device)
     f32 = lambda v: float(np.float32(v))
     with torch.cuda.device(device):
         rc = _native.lib().uoc_prep_rgbd(_native.ptr(bgr), _native.ptr(dep), H, W, f32(cam["fx"]), f32(cam["fy"]),
