@@ -200,8 +200,10 @@ class _HostMirror:
         self.stats_all = torch.empty((frames, n), dtype=torch.int32).pin_memory()
         self.plans = torch.empty((frames, n), dtype=torch.int32).pin_memory()
         self.table, self.stats, self.plan = self.tables[0], self.stats_all[0], self.plans[0]
-        self.table_ready = torch.cuda.Event()
-        self.stats_ready = torch.cuda.Event()
+        # blocking events: a host thread that waits on one sleeps instead of spinning (the runner's core budget per rank)
+        blocking = os.environ.get("UOC_PIPE_BLOCKING_EVENTS", "0") == "1"
+        self.table_ready = torch.cuda.Event(blocking=blocking)
+        self.stats_ready = torch.cuda.Event(blocking=blocking)
 
 
 _mirrors = {}
