@@ -392,6 +392,8 @@ def compact_line(full, full_path):
     out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                 "scaling", "vs_baseline", "dtype", "data")}
     out["config"] = full["config"]
+    if full.get("experiment"):
+        out["experiment"] = full["experiment"][:120]
     roof = full.get("roofline")
     out["roofline"] = _pick(roof, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes", "avg_launch_us",
                                    "gpu_time_share", "algorithmic_tflops", "matrix_pipe_tflops", "matrix_pipe_frac"))
@@ -654,6 +656,9 @@ def _main():
     ap.add_argument("--skip-latency", action="store_true", help="skip the one-frame-at-a-time latency leg (profiling runs)")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-out", default="", help=argparse.SUPPRESS)
+    ap.add_argument("--split-precision", action="store_true",
+                    help="EXPERIMENT, never the headline: plane GEMMs in split precision (bf16 x 3, fp32 accumulation); the line "
+                         "then says dtype 'bf16x3' and carries an 'experiment' key")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dist-timeout", type=float, default=float(os.environ.get("UOC_BENCH_DIST_TIMEOUT", "300")),
                     help="seconds the rendezvous and every collective may take before the run fails with an error record")
@@ -737,6 +742,8 @@ def _main():
         from unseenobjectclustering_amd import _native, networks, synth
         from unseenobjectclustering_amd.fcn.config import cfg
         cfg.device = device
+        if args.split_precision:
+            cfg.TEST.SPLIT_PRECISION_GEMM = True        # read by SEGNET at construction
         sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
         network = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
         network_crop = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
@@ -1006,7 +1013,7 @@ def _main():
             "metric": METRIC,
             "value": round(total / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / K, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (stub frame function, CPU plumbing test)" if stub else ""),
+            "vs_baseline": None, "dtype": "bf16x3" if args.split_precision else "f32", "data": "synthetic" + (" (stub frame function, CPU plumbing test)" if stub else ""),
             "config": {"workload": workload, "frame": "640x480", "seeds": 100, "iters": 10, "crop": 224,
                        "total_frames": total, "frames_per_gpu": K, "collective": bool(use_dist),
                        "frames_in_flight_per_gpu": args.inflight * args.frames_per_launch,
@@ -1018,6 +1025,9 @@ def _main():
             "cpu_baseline": cpu, "parity": parity, "kernels": kernels, "kernels_pipe": kernels_pipe, "conv_by_shape": by_shape if lead and args.profile_steps > 0 else None,
             "clustering_by_shape": clustering_by_shape if lead and args.profile_steps > 0 else None,
         }
+        if args.split_precision:
+            line["experiment"] = ("split-precision plane GEMMs (csrc/wino4_split.hip): every fp32 operand as three bf16 terms, six bf16 "
+                                  "MFMA products, fp32 accumulation; NOT the shipped default, NOT comparable as `value`")
     else:
         line = None
     if use_dist:

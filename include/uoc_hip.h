@@ -148,6 +148,12 @@ size_t uoc_net_workspace_bytes(const uoc_net *net, int B, int H, int W);
  * the one the mode does not read (d_xyz for COLOR, d_rgb for DEPTH) may be NULL.
  * d_embed: [B][H*W][64] pixel-major unit-norm embeddings; RGBD_CAT: [B][2][H*W][64], plane 0 = the image
  * branch's 64 channels, plane 1 = the XYZ branch's, normalised over all 128 (the layout uoc_ms_cluster_wide reads). */
+/* EXPERIMENT (round 6), off by default and never part of the headline measurement: the plane GEMMs of the Winograd layers in
+ * split precision — every fp32 operand as three bf16 terms (3 x 8 = 24 significand bits), six bf16 MFMA products with fp32
+ * accumulation, 2.67x the fp32 matrix rate (csrc/wino4_split.hip).  Embeddings stay within the fp32 path's distance of an
+ * fp64 evaluation, but they are NOT bit-identical to it.  Call after uoc_net_finalize; on = 1 splits the transformed
+ * weights once (hipMalloc + a synchronisation). */
+int uoc_net_set_split_precision(uoc_net *net, int on);
 int uoc_net_forward(uoc_net *net, const float *d_rgb, const float *d_xyz, int B, int H, int W, float *d_embed,
                     void *d_ws, size_t ws_bytes, void *stream);
 
@@ -160,6 +166,7 @@ int uoc_net_forward(uoc_net *net, const float *d_rgb, const float *d_xyz, int B,
  * scratch in buffers owned by this entry: one caller thread at a time. */
 #define UOC_CONV_DIRECT 0
 #define UOC_CONV_WINOGRAD4 4
+#define UOC_CONV_WINOGRAD4_BF16X3 5   /* EXPERIMENT: the same with the split-precision plane GEMM (see uoc_net_set_split_precision) */
 int uoc_conv2d_nhwc(const float *d_in, const float *d_w, const float *d_bias, const float *d_res, float *d_out,
                     int G, int B, int H, int W, int Cin, int Cout, int K, int stride, int dil, int pad, int relu,
                     void *stream);

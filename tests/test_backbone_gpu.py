@@ -229,3 +229,45 @@ def test_winograd4_edge_cases(device):
     sliced = _wino4_conv(device, x, w, b, res, 2, True, algo=_native.CONV_DIRECT, env={"UOC_SPLIT_MAX_MB": "2"})
     assert torch.equal(whole, sliced)
     assert (whole - ref).abs().max().item() < 2e-4 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("case", WINO_CASES + WINO4_EXTRA_CASES)
+def test_split_precision_plane_gemm_vs_fp32(device, case):
+    """EXPERIMENT (round 6, csrc/wino4_split.hip): the Winograd layer with its plane GEMM in split precision — three bf16 terms
+    per fp32 operand, six bf16 MFMA products, fp32 accumulation — against torch CPU conv2d (the bar of the fp32 path: 2e-4 of the
+    output scale) and against the fp32 Winograd path itself (the dropped terms are <= 2^-24 relative per product: bar 2e-5 of
+    the scale, measured ~1e-6)."""
+    G, B, H, W, Cin, Cout, dil, use_res, relu = case
+    g = torch.Generator().manual_seed(abs(hash(case)) % (2 ** 31))
+    x = torch.randn(G, B, Cin, H, W, generator=g)
+    w = torch.randn(G, Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(G, Cout, generator=g)
+    res = torch.randn(G, B, Cout, H, W, generator=g) if use_res else None
+    ref = torch.stack([F.conv2d(x[i], w[i], b[i], padding=dil, dilation=dil) for i in range(G)])
+    if res is not None:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    fp32 = _wino4_conv(device, x, w, b, res, dil, relu)
+    got = _wino4_conv(device, x, w, b, res, dil, relu, algo=_native.CONV_WINOGRAD4_BF16X3)
+    scale = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < 2e-4 * scale
+    assert (got - fp32).abs().max().item() < 2e-5 * scale, (got - fp32).abs().max().item()
+
+
+def test_split_precision_network_vs_oracle(device):
+    """The whole two-branch network with split-precision plane GEMMs: embeddings within the north_star's 1e-3 of the oracle's
+    (measured next to the fp32 path's error in the assertion message)."""
+    net, sd = _net(5, device)
+    fr = synth.rgbd_frame(12, 120, 88, 3)
+    img, dep = torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"])
+    want = BO.segnet_forward(sd, img, dep)
+    e32 = (net(img.to(device), None, dep.to(device)).cpu() - want).abs().max().item()
+    try:
+        net.set_split_precision(True)
+        e3 = (net(img.to(device), None, dep.to(device)).cpu() - want).abs().max().item()
+    finally:
+        net.set_split_precision(False)
+    back = (net(img.to(device), None, dep.to(device)).cpu() - want).abs().max().item()
+    assert e3 < EMBED_TOL and back == e32, (e32, e3, back)
+    assert e3 < 10 * max(e32, 1e-6), f"split precision {e3:.2e} vs fp32 {e32:.2e}"

@@ -57,6 +57,8 @@ def _declare(lib):
     lib.uoc_net_workspace_bytes.restype = c_size_t
     lib.uoc_net_workspace_bytes.argtypes = [P, c_int, c_int, c_int]
     lib.uoc_net_forward.argtypes = [P, P, P, c_int, c_int, c_int, P, P, c_size_t, P]
+    lib.uoc_net_set_split_precision.argtypes = [P, c_int]
+    lib.uoc_net_set_split_precision.restype = c_int
     lib.uoc_conv2d_nhwc.argtypes = [P, P, P, P, P] + [c_int] * 11 + [P]
     lib.uoc_conv2d_nhwc_algo.argtypes = [P, P, P, P, P] + [c_int] * 12 + [P]
     lib.uoc_conv2d_nhwc_algo.restype = c_int
@@ -98,7 +100,7 @@ EXPORTED_SYMBOLS = (
     "uoc_ms_seed_components", "uoc_ms_assign", "uoc_ms_cluster", "uoc_ms_workspace_bytes_wide", "uoc_ms_cluster_wide",
     "uoc_net_embed_dim",
     "uoc_net_create", "uoc_net_create_mode", "uoc_net_destroy", "uoc_net_load_param", "uoc_net_finalize", "uoc_net_workspace_bytes",
-    "uoc_net_forward", "uoc_conv2d_nhwc", "uoc_conv2d_nhwc_algo",
+    "uoc_net_forward", "uoc_net_set_split_precision", "uoc_conv2d_nhwc", "uoc_conv2d_nhwc_algo",
     "uoc_roi_workspace_bytes", "uoc_prep_rgbd", "uoc_filter_labels_depth", "uoc_roi_build", "uoc_roi_crop", "uoc_roi_match_stats",
     "uoc_roi_paste", "uoc_roi_match", "uoc_labels_to_u8", "uoc_eval_workspace_bytes", "uoc_eval_pair_stats", "uoc_lzf_decompress", "uoc_prof_enable", "uoc_prof_reset", "uoc_prof_report",
 )
@@ -131,7 +133,7 @@ def lib():
     return _lib
 
 
-CONV_DIRECT, CONV_WINOGRAD4 = 0, 4       # include/uoc_hip.h: UOC_CONV_*
+CONV_DIRECT, CONV_WINOGRAD4, CONV_WINOGRAD4_BF16X3 = 0, 4, 5       # include/uoc_hip.h: UOC_CONV_*
 
 
 def config_fingerprint() -> int:

@@ -33,7 +33,14 @@ bool wino4_eligible(const ConvParams &p);
 bool wino4_channels_ok(int Cin, int Cout);
 size_t wino4_ws_floats(int G, int B, int H, int W, int d, int Cin, int Cout);
 int launch_wino4_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st);
-int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_t st);
+// U3 != nullptr: the split-precision ("bf16x3") plane GEMM of csrc/wino4_split.hip with the weights split by
+// launch_wino4_split_weights ([G*36][3][Cout][Cin] bf16) — an experiment, never the default
+int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_t st, const unsigned short *U3 = nullptr);
+int launch_wino4_split_weights(const float *U, unsigned short *U3, int G, int Cout, int Cin, hipStream_t st);
+int launch_wino4_slice_split(const ConvParams &p0, int Bg, int b0, const unsigned short *U3, float *ws, hipStream_t st);
+struct Wino4Geom;
+int w4_stage_output(const ConvParams &p, const Wino4Geom &geo, const float *Mw, hipStream_t st);
+long wino4_elem_blocks(long items);
 // NCHW [B][3][H][W] -> NHWC4 [B][H][W][4] (4th channel = 0)
 int launch_nchw3_to_nhwc4(const float *in, float *out, int B, int H, int W, hipStream_t st);
 // 3x3 s2 p1 max pooling, NHWC, C % 4 == 0; `n_img` images

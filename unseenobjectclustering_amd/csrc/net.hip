@@ -25,6 +25,7 @@ struct ConvLayer {
   bool has_bn, has_bias, stem;
   float *d_w = nullptr, *d_b = nullptr;  // [G][...]
   float *d_U4 = nullptr;                 // Winograd F(4x4) weights [G*36][Cout][Cin] (eligible layers, wino_f == 4)
+  unsigned short *d_U3 = nullptr;        // the same split into three bf16 planes (uoc_net_set_split_precision; csrc/wino4_split.hip)
   size_t w_per_group = 0;
 };
 
@@ -45,6 +46,7 @@ struct uoc_net {
   // variable may change a result).
   const int wino_min_cin = 64;   // 3x3 stride-1 layers with Cin >= this run as Winograd convolutions (round 4: 64, was 128)
   const int wino_f = 4;          // output tile of the Winograd path: F(4x4,3x3) (csrc/wino4.hip)
+  bool split = false;      // EXPERIMENT: plane GEMMs in split precision (three bf16 terms per fp32 operand, fp32 accumulation)
   int mode = UOC_NET_RGBD_ADD;
   int G = 2;  // backbones evaluated side by side (2 for RGBD 'add' and 'cat')
 };
@@ -265,9 +267,10 @@ static ConvParams conv_params(int G, const ConvLayer &L, const float *in, const 
 }
 
 static int run_conv(int G, const ConvLayer &L, const float *in, const float *res, float *out, int B, int H, int W,
-                    int Ho, int Wo, hipStream_t st, float *wino_ws = nullptr) {
+                    int Ho, int Wo, hipStream_t st, float *wino_ws = nullptr, bool split = false) {
   const ConvParams p = conv_params(G, L, in, res, out, B, H, W, Ho, Wo);
-  if (L.d_U4 && wino_ws && wino4_eligible(p)) return launch_wino4_conv(p, L.d_U4, wino_ws, st);
+  if (L.d_U4 && wino_ws && wino4_eligible(p))
+    return launch_wino4_conv(p, L.d_U4, wino_ws, st, split ? L.d_U3 : nullptr);
   return launch_conv(p, st);
 }
 
@@ -294,6 +297,21 @@ int uoc_net_create_mode(uoc_net **out, int mode) {
   return UOC_OK;
 }
 
+int uoc_net_set_split_precision(uoc_net *n, int on) {
+  UOC_REQUIRE(n && n->finalized, "uoc_net_set_split_precision: the network must be finalized");
+  if (on) {
+    for (auto &L : n->layers) {
+      if (!L.d_U4 || L.d_U3) continue;
+      const size_t elems = (size_t)n->G * 36 * 3 * L.Cout * L.Cin;
+      UOC_HIP_CHECK(hipMalloc(&L.d_U3, elems * sizeof(unsigned short)));
+      if (int rc = launch_wino4_split_weights(L.d_U4, L.d_U3, n->G, L.Cout, L.Cin, nullptr)) return rc;
+    }
+    UOC_HIP_CHECK(hipDeviceSynchronize());
+  }
+  n->split = on != 0;
+  return UOC_OK;
+}
+
 int uoc_net_embed_dim(const uoc_net *n) { return n && n->mode == UOC_NET_RGBD_CAT ? 128 : 64; }
 
 int uoc_net_destroy(uoc_net *n) {
@@ -302,6 +320,7 @@ int uoc_net_destroy(uoc_net *n) {
     if (L.d_w) (void)hipFree(L.d_w);
     if (L.d_b) (void)hipFree(L.d_b);
     if (L.d_U4) (void)hipFree(L.d_U4);
+    if (L.d_U3) (void)hipFree(L.d_U3);
   }
   delete n;
   return UOC_OK;
@@ -371,13 +390,13 @@ int uoc_net_forward(uoc_net *n, const float *d_rgb, const float *d_xyz, int B, i
     const ConvLayer &c1 = n->layers[b.conv1], &c2 = n->layers[b.conv2];
     const int ho = (h - 1) / c1.stride + 1, wo = (wd - 1) / c1.stride + 1;
     float *x = w.buf[cur], *tmp = w.buf[(cur + 1) & 3], *sc = w.buf[(cur + 2) & 3], *y = w.buf[(cur + 3) & 3];
-    if (int rc = run_conv(G, c1, x, nullptr, tmp, B, h, wd, ho, wo, st, w.wino)) return rc;
+    if (int rc = run_conv(G, c1, x, nullptr, tmp, B, h, wd, ho, wo, st, w.wino, n->split)) return rc;
     const float *res = x;
     if (b.down >= 0) {   // 1x1 (possibly strided) shortcut + BN (resnet.py:215-219)
       if (int rc = run_conv(G, n->layers[b.down], x, nullptr, sc, B, h, wd, ho, wo, st)) return rc;
       res = sc;
     }
-    if (int rc = run_conv(G, c2, tmp, res, y, B, ho, wo, ho, wo, st, w.wino)) return rc;
+    if (int rc = run_conv(G, c2, tmp, res, y, B, ho, wo, ho, wo, st, w.wino, n->split)) return rc;
     cur = (cur + 3) & 3;
     h = ho;
     wd = wo;
@@ -422,10 +441,11 @@ int uoc_conv2d_nhwc_algo(const float *d_in, const float *d_w, const float *d_bia
   // one caller thread at a time, as the header says — the mutex makes a violation slow instead of wrong
   static std::mutex mu;
   std::lock_guard<std::mutex> lock(mu);
-  if (algo == UOC_CONV_WINOGRAD4) {
+  if (algo == UOC_CONV_WINOGRAD4 || algo == UOC_CONV_WINOGRAD4_BF16X3) {
     UOC_REQUIRE(wino4_eligible(p), "conv2d: shape not eligible for Winograd F(4x4,3x3)");
     static float *U4 = nullptr, *ws4 = nullptr;
-    static size_t ucap4 = 0, wcap4 = 0;
+    static unsigned short *U3 = nullptr;
+    static size_t ucap4 = 0, wcap4 = 0, ucap3 = 0;
     const size_t un = (size_t)G * 36 * Cout * Cin, wn = wino4_ws_floats(G, B, H, W, dil, Cin, Cout);
     if (un > ucap4) {
       if (U4) (void)hipFree(U4);
@@ -439,6 +459,15 @@ int uoc_conv2d_nhwc_algo(const float *d_in, const float *d_w, const float *d_bia
     }
     // always re-transform: callers reuse device addresses with new weights
     if (int rc = launch_wino4_weights(d_w, U4, G, Cout, Cin, st)) return rc;
+    if (algo == UOC_CONV_WINOGRAD4_BF16X3) {
+      if (3 * un > ucap3) {
+        if (U3) (void)hipFree(U3);
+        UOC_HIP_CHECK(hipMalloc(&U3, 3 * un * sizeof(unsigned short)));
+        ucap3 = 3 * un;
+      }
+      if (int rc = launch_wino4_split_weights(U4, U3, G, Cout, Cin, st)) return rc;
+      return launch_wino4_conv(p, U4, ws4, st, U3);
+    }
     return launch_wino4_conv(p, U4, ws4, st);
   }
   set_error("conv2d: unknown algorithm %d", algo);

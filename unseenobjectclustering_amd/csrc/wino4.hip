@@ -481,7 +481,8 @@ bool wino4_eligible(const ConvParams &p) {
 
 size_t wino4_ws_floats(int G, int B, int H, int W, int d, int Cin, int Cout) {
   const Wino4Geom geo = make_geom4(B, H, W, d);
-  return (size_t)G * 36 * geo.NT * 2 * (size_t)(Cin > Cout ? Cin : Cout);   // two halves: V planes, M planes
+  // V planes + M planes; the split-precision experiment stores V as three bf16 planes (1.5x) -> 2.5 units + alignment slack
+  return (size_t)G * 36 * geo.NT * 5 / 2 * (size_t)(Cin > Cout ? Cin : Cout) + 64;
 }
 
 int launch_wino4_weights(const float *w, float *U, int G, int Cout, int Cin, hipStream_t st) {
@@ -496,7 +497,7 @@ int launch_wino4_weights(const float *w, float *U, int G, int Cout, int Cin, hip
 // Grid of the two elementwise kernels: every thread owns one (tile, channel quad) item at a time; the grid is capped at
 // the blocks that are resident at once (2 per CU at ~200 VGPRs) so that all blocks walk equally long item ranges and
 // finish together instead of leaving a half-empty last round.
-static long wino4_elem_blocks(long items) {
+long wino4_elem_blocks(long items) {
   long blocks = (items + 255) / 256;
   const long cap = 16384;
   blocks = blocks < cap ? blocks : cap;
@@ -505,14 +506,14 @@ static long wino4_elem_blocks(long items) {
 
 static int launch_wino4_slice(const ConvParams &p0, int Bg, int b0, const float *U, float *ws, hipStream_t st);
 
-int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_t st) {
+int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_t st, const unsigned short *U3) {
   UOC_REQUIRE(wino4_eligible(p), "winograd F(4x4): layer not eligible");
   UOC_REQUIRE(U && ws && p.in && p.out, "winograd F(4x4): null tensor/weight/workspace pointer");
   const int planes = 36 * p.G;
   UOC_REQUIRE((size_t)planes * p.Cout * p.Cin * 4 < (1ull << 32), "winograd F(4x4): weight planes exceed 4 GB");
   // The plane GEMM addresses V and M with 32-bit buffer offsets: a batch whose frequency planes exceed 4 GB is run as
   // several launches over slices of the batch (same tiles, same arithmetic: a tile never spans two images).
-  const size_t per_image = (size_t)planes * make_geom4(1, p.H, p.W, p.dil).NT * (p.Cin > p.Cout ? p.Cin : p.Cout) * 4;
+  const size_t per_image = (size_t)planes * make_geom4(1, p.H, p.W, p.dil).NT * (p.Cin > p.Cout ? p.Cin : p.Cout) * (U3 ? 6 : 4);
   UOC_REQUIRE(per_image < (1ull << 32), "winograd F(4x4): one image's frequency planes exceed 4 GB");
   static EnvInt limit_mb("UOC_SPLIT_MAX_MB", 0);   // tests: a smaller limit, to exercise the split on small batches (same results)
   const size_t limit = limit_mb.get() > 0 && ((size_t)limit_mb.get() << 20) > per_image ? (size_t)limit_mb.get() << 20 : (1ull << 32) - 1;
@@ -521,11 +522,11 @@ int launch_wino4_conv(const ConvParams &p, const float *U, float *ws, hipStream_
     for (int b0 = 0; b0 < p.B; b0 += bmax) {
       ConvParams q = p;
       q.B = p.B - b0 < bmax ? p.B - b0 : bmax;
-      if (int rc = launch_wino4_slice(q, p.B, b0, U, ws, st)) return rc;
+      if (int rc = U3 ? launch_wino4_slice_split(q, p.B, b0, U3, ws, st) : launch_wino4_slice(q, p.B, b0, U, ws, st)) return rc;
     }
     return UOC_OK;
   }
-  return launch_wino4_slice(p, p.B, 0, U, ws, st);
+  return U3 ? launch_wino4_slice_split(p, p.B, 0, U3, ws, st) : launch_wino4_slice(p, p.B, 0, U, ws, st);
 }
 
 // ---- the three stages of one layer ---------------------------------------------------------------------------------
@@ -554,7 +555,7 @@ static int w4_stage_gemm(const ConvParams &p, const Wino4Geom &geo, const float 
   return launch_wino4_gemm(V, U, Mw, geo.NT, p.Cin, p.Cout, planes, st);
 }
 
-static int w4_stage_output(const ConvParams &p, const Wino4Geom &geo, const float *Mw, hipStream_t st) {
+int w4_stage_output(const ConvParams &p, const Wino4Geom &geo, const float *Mw, hipStream_t st) {
   const double Mpix = (double)p.B * p.H * p.W;
   const ProfTag tag = {{geo.NT, p.Cin, p.Cout, p.dil}};
   const int vec = w4_vec();

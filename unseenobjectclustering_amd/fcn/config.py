@@ -57,6 +57,9 @@ cfg.TEST.IMS_PER_BATCH = 1             # config.py:330
 # to the eager path but measured no faster (7.78 vs 7.76 ms per frame, profiles/r06_latency.md — the frame is kernel-bound once
 # the ROI ordering runs on the device), and captured graphs in a process cost its multi-stream throughput schedule 5 %.
 cfg.TEST.GRAPH_REPLAY = os.environ.get("UOC_GRAPH_REPLAY", "0") == "1"
+# EXPERIMENT (no reference counterpart; never the default, never the headline): newly built SEGNETs run their Winograd plane GEMMs in
+# split precision (bf16 x 3, fp32 accumulation; csrc/wino4_split.hip).  UOC_SPLIT_GEMM=1 runs a whole test / bench session that way.
+cfg.TEST.SPLIT_PRECISION_GEMM = os.environ.get("UOC_SPLIT_GEMM", "0") == "1"
 cfg.TEST.ROS_CAMERA = "camera"         # config.py:327 ('D415' | 'Azure' | a kinect-style namespace)
 cfg.TEST.SCALES_BASE = (0.25, 0.5, 1.0, 2.0, 3.0)   # config.py:353 (every shipped yml sets (1.0,))
 cfg.TEST.CLASSES = (0, 1, 2, 3)        # config.py:346 (if emptied, tools/test_net.py:68-69 copies TRAIN.CLASSES)

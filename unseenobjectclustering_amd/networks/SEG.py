@@ -81,6 +81,8 @@ class SEGNET(nn.Module):
         self._handle = None
         self._handle_device = None
         self._native_gen = 0          # bumped whenever the native weight copy is rebuilt (captured hipGraphs bake its pointers)
+        # EXPERIMENT (never the default, never the headline): plane GEMMs in split precision (uoc_net_set_split_precision)
+        self.split_precision = bool(getattr(cfg.TEST, "SPLIT_PRECISION_GEMM", False))
         self.train(False)
 
     # -- native network management -----------------------------------------------------------
@@ -101,6 +103,16 @@ class SEGNET(nn.Module):
         self._release()           # weights changed: rebuild the native copy on next forward
         return out
 
+    def set_split_precision(self, on: bool):
+        """EXPERIMENT: run the Winograd layers' plane GEMMs in split precision (three bf16 terms per fp32 operand, six bf16 MFMA
+        products, fp32 accumulation; csrc/wino4_split.hip).  Not bit-identical to the fp32 path; reported under its own key."""
+        self.split_precision = bool(on)
+        if self._handle is not None:
+            with torch.cuda.device(self._handle_device):
+                _native.check(_native.lib().uoc_net_set_split_precision(self._handle, 1 if on else 0), "uoc_net_set_split_precision")
+            self._native_gen += 1         # captured graphs bake the launch sequence
+        return self
+
     def refresh(self):
         """Drop the native weight copy (call after mutating parameters in place)."""
         self._release()
@@ -120,6 +132,9 @@ class SEGNET(nn.Module):
                           f"uoc_net_load_param({key})")
         with torch.cuda.device(device):
             _native.check(L.uoc_net_finalize(h), "uoc_net_finalize")
+        if getattr(self, "split_precision", False):
+            with torch.cuda.device(device):
+                _native.check(L.uoc_net_set_split_precision(h, 1), "uoc_net_set_split_precision")
         self._handle = h
         self._handle_device = device
         self._native_gen = getattr(self, "_native_gen", 0) + 1
