@@ -1025,6 +1025,9 @@ def _main():
             "cpu_baseline": cpu, "parity": parity, "kernels": kernels, "kernels_pipe": kernels_pipe, "conv_by_shape": by_shape if lead and args.profile_steps > 0 else None,
             "clustering_by_shape": clustering_by_shape if lead and args.profile_steps > 0 else None,
         }
+        if args.split_precision and line.get("roofline"):
+            line["roofline"]["note"] = ("EXPERIMENT: the plane GEMM issues six bf16 MFMA products per fp32 product on the bf16 pipe; `achieved` / "
+                                        "`frac` are still computed against the fp32 peak and are NOT a roofline fraction in this mode")
         if args.split_precision:
             line["experiment"] = ("split-precision plane GEMMs (csrc/wino4_split.hip): every fp32 operand as three bf16 terms, six bf16 "
                                   "MFMA products, fp32 accumulation; NOT the shipped default, NOT comparable as `value`")

@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import backbone_oracle as BO
+from unseenobjectclustering_amd.fcn.config import cfg
 from unseenobjectclustering_amd import _native, networks, synth
 
 pytestmark = pytest.mark.gpu
@@ -262,6 +263,7 @@ def test_split_precision_network_vs_oracle(device):
     fr = synth.rgbd_frame(12, 120, 88, 3)
     img, dep = torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"])
     want = BO.segnet_forward(sd, img, dep)
+    net.set_split_precision(False)          # (a session run with UOC_SPLIT_GEMM=1 builds its networks in split mode)
     e32 = (net(img.to(device), None, dep.to(device)).cpu() - want).abs().max().item()
     try:
         net.set_split_precision(True)
@@ -269,5 +271,6 @@ def test_split_precision_network_vs_oracle(device):
     finally:
         net.set_split_precision(False)
     back = (net(img.to(device), None, dep.to(device)).cpu() - want).abs().max().item()
+    net.set_split_precision(bool(cfg.TEST.SPLIT_PRECISION_GEMM))
     assert e3 < EMBED_TOL and back == e32, (e32, e3, back)
     assert e3 < 10 * max(e32, 1e-6), f"split precision {e3:.2e} vs fp32 {e32:.2e}"
