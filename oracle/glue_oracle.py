@@ -167,3 +167,41 @@ def test_segnet(test_loader, network, network_crop, rng: np.random.RandomState):
         prediction = out_label.squeeze().numpy()
         out.append((prediction, refined.squeeze().numpy() if refined is not None else prediction.copy()))
     return out
+
+
+def cpython_sort_small(keys):
+    """list.sort(reverse=True) of range(len(keys)) by keys[i] for n < 64, restated from CPython's Objects/listobject.c
+    (reverse the list, count_run, binary insertion sort with `<` only, reverse again; minrun = n below 64) — the algorithm
+    csrc/roi.hip::cpython_sort_small runs on the device when a ROI sort key is NaN (lib/fcn/test_dataset.py:135 can yield one
+    and :148 sorts with Python's own sort, whose result for NaN keys is whatever this algorithm does).  Test infrastructure:
+    tests/test_oracle_glue.py pins it to Python's sorted() here; the GPU test pins the kernel to Python's sorted() there."""
+    n = len(keys)
+    assert n < 64
+    a = [(keys[i], i) for i in range(n)]
+    lt = lambda x, y: bool(x[0] < y[0])
+
+    def rev(lo, hi):
+        a[lo:hi] = a[lo:hi][::-1]
+    rev(0, n)
+    if n >= 2:
+        run, desc = 2, lt(a[1], a[0])
+        lo = 2
+        while lo < n:
+            if desc != lt(a[lo], a[lo - 1]):
+                break
+            lo += 1
+            run += 1
+        if desc:
+            rev(0, run)
+        for start in range(run, n):
+            l, r, pivot = 0, start, a[start]
+            while l < r:
+                p = l + ((r - l) >> 1)
+                if lt(pivot, a[p]):
+                    r = p
+                else:
+                    l = p + 1
+            a[l + 1:start + 1] = a[l:start]
+            a[l] = pivot
+    rev(0, n)
+    return [i for _, i in a]

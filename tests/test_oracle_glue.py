@@ -49,3 +49,23 @@ def test_test_sample_oracle_matches_reference(golden_dir, name):
     out_label, refined = G.test_sample(torch.from_numpy(fr["image_color"]), torch.from_numpy(fr["depth"]), net, net_crop, rng)
     assert np.array_equal(out_label.numpy().astype(np.uint8), g[name + "/out_label"])
     assert np.array_equal(refined.numpy().astype(np.uint8), g[name + "/refined"])
+
+
+def test_cpython_short_list_sort_restatement_equals_sorted():
+    """The restatement of CPython's list.sort for n < 64 (oracle/glue_oracle.py, mirrored by csrc/roi.hip for NaN sort keys) gives
+    exactly sorted(..., reverse=True) — with ties and with NaN keys, where every comparison is false and only the algorithm itself
+    defines the result (lib/fcn/test_dataset.py:135,148)."""
+    import random
+    import torch
+    from oracle import glue_oracle as G
+    rng = random.Random(5)
+    for trial in range(3000):
+        n = rng.randint(0, 63)
+        pool = [round(rng.random(), 1) for _ in range(max(1, n // 3))]
+        keys = [float("nan") if rng.random() < rng.choice([0.0, 0.2, 0.8]) else rng.choice(pool) for _ in range(n)]
+        want = [i for i, _ in sorted([(i, k) for i, k in enumerate(keys)], key=lambda x: x[1], reverse=True)]
+        assert G.cpython_sort_small(keys) == want, (keys, want)
+    # 0-dim float32 tensors as keys, like the reference's avg_depth values
+    keys = [torch.tensor(v, dtype=torch.float32) for v in (0.5, float("nan"), 0.7, 0.5, float("nan"), 0.1)]
+    want = [i for i, _ in sorted([(i, k) for i, k in enumerate(keys)], key=lambda x: x[1], reverse=True)]
+    assert G.cpython_sort_small(keys) == want
