@@ -107,3 +107,45 @@ def test_rank_views_concatenate_to_the_single_rank_block(device):
         got = torch.cat(parts)
         assert got.shape == whole.shape
         assert torch.equal(got, whole), f"world={world}: the concatenated rank blocks differ from the single-rank block"
+
+
+def test_host_order_and_the_rerun_when_the_device_ordering_flags_a_block(device):
+    """Round 6: (a) the ROI paint order on the host (rounds 1-5, FORCE_HOST_ORDER) and on the device (uoc_roi_match) give the same
+    block; (b) when a block ends with the ordering flag up — NaN sort keys with >= 64 ROIs, the one case the kernel leaves to
+    Python's own sort — run_sharded runs it again with the host ordering, same seeds, and does not double-count the ROIs.  The flag
+    is raised artificially here (the kernel's own flagging is covered by test_device_roi_order_is_pythons_sorted)."""
+    from unseenobjectclustering_amd.fcn import test_dataset as TD
+    cfg.device = device
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.calibrated_state_dict().items()}
+    net = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    net_crop = networks.seg_resnet34_8s_embedding(2, 64, sd).eval()
+    samples = []
+    for g in range(6):
+        fr = synth.palette_frame(10_100 + g, 240, 320, 4 + g % 3)
+        samples.append(dict(image_color=torch.from_numpy(fr["image_color"]).to(device), depth=torch.from_numpy(fr["depth"]).to(device)))
+    fn = runner.two_stage_frame_fn(samples, net, net_crop, frames_per_launch=2)
+    want = runner.run_sharded(6, fn, 240, 320, device, 0, 1, False, inflight=3).cpu()
+    counts = list(fn.roi_counts)
+    assert len(counts) == 6 and max(counts) >= 1
+    was = TD.FORCE_HOST_ORDER
+    try:
+        TD.FORCE_HOST_ORDER = True
+        fn2 = runner.two_stage_frame_fn(samples, net, net_crop, frames_per_launch=2)
+        assert torch.equal(runner.run_sharded(6, fn2, 240, 320, device, 0, 1, False, inflight=3).cpu(), want)
+        assert torch.equal(runner.run_sharded(6, fn2, 240, 320, device, 0, 1, False, inflight=1).cpu(), want)
+    finally:
+        TD.FORCE_HOST_ORDER = was
+    # (b) one artificial flag: the first pass of the block "fails" with HostOrderNeeded, the second runs with the host ordering
+    fn3 = runner.two_stage_frame_fn(samples, net, net_crop, frames_per_launch=2)
+    seen = []
+    real_finish = fn3.finish
+
+    def finish(dev):
+        seen.append(TD.FORCE_HOST_ORDER)
+        real_finish(dev)
+        if len(seen) == 1:
+            raise TD.HostOrderNeeded("injected")
+    fn3.finish = finish
+    got = runner.run_sharded(6, fn3, 240, 320, device, 0, 1, False, inflight=3).cpu()
+    assert seen == [False, True] and TD.FORCE_HOST_ORDER is was
+    assert torch.equal(got, want) and list(fn3.roi_counts) == counts
