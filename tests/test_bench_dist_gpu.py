@@ -89,3 +89,24 @@ def test_eight_ranks_on_one_gpu_match_the_single_rank_block(tmp_path, device):
     json.dump({"world": 8, "frames": 64, "per_rank": eight["per_rank"], "frames_per_s_eight_ranks_one_gpu": eight["value"],
                "frames_per_s_one_rank": one["value"], "one_rank": one["per_rank"]},
               open(os.path.join(ROOT, "gpurun_out", "eight_ranks_one_gpu.json"), "w"))
+
+
+def test_a_multi_rank_record_carries_roofline_cpu_baseline_and_parity(tmp_path, device):
+    """at world > 1 rank 0 still fills the three record blocks north_star wants "in the same run" — the profiled
+    pass (roofline + kernel shares), the CPU baseline and the parity of its first frames — after the gather, while the other ranks
+    are done.  Two ranks on GPU 0 (UOC_BENCH_ONE_DEVICE=1, gloo)."""
+    env = dict(os.environ, UOC_BENCH_ONE_DEVICE="1", UOC_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "UOC_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--frames", "16", "--warmup", "1",
+                        "--cpu-frames", "1", "--profile-steps", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1 and len(line[0]) < 3000
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and len(d["per_rank"]) == 2
+    assert d["roofline"] and d["roofline"]["kernel"] == "wino4_gemm" and 0.05 < d["roofline"]["frac"] < 1.0     # (one launch set on a GPU two ranks share: the VALUE means nothing here)
+    assert d["cpu_baseline"] and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port"
+    assert d["parity"] and d["parity"]["frames"] == 1 and d["parity"]["embed_max_err"] < 1e-3
+    assert d["kernel_time_share"] and d.get("kernel_time_share_pipe")
+    assert d["latency"] is None and d["sustained_frames_per_s"] is None      # the N = 1 legs stay N = 1 legs
