@@ -68,6 +68,13 @@ def test_argument_validation_without_gpu():
     assert lib.uoc_eval_workspace_bytes(480, 640) >= 2 * 480 * 640 * 4
     assert lib.uoc_eval_pair_stats(None, None, 480, 640, 3, None, None, 0, None) == -22
     assert lib.uoc_roi_crop(None, None, None, 480, 640, None, 1, 224, None, None, None, None) == -22
+    # round 6: the device-side match_label_crop and the split-precision switch validate first, too
+    assert lib.uoc_roi_match(None, None, None, None, 1, 224, 480, 640, None, None, None, None, None, 0, None) == -22
+    assert lib.uoc_net_set_split_precision(None, 1) == -22
+    h = ctypes.c_void_p()
+    assert lib.uoc_net_create(ctypes.byref(h)) == 0
+    assert lib.uoc_net_set_split_precision(h, 1) == -22            # not finalized
+    assert lib.uoc_net_destroy(h) == 0
 
 
 def test_shipped_library_has_no_result_affecting_knobs():
