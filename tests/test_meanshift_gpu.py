@@ -160,6 +160,47 @@ def test_converged_seeds_do_not_depend_on_the_batch(device, shape):
         assert torch.equal(sb[pos], s1[0])
 
 
+def _hill_climb_raw(X, Z0, iters=10):
+    from unseenobjectclustering_amd import _native
+    L = _native.lib()
+    batch, n, _ = X.shape
+    ws = MS._workspace(X.device, L.uoc_ms_workspace_bytes(batch, n, Z0.shape[1]))
+    Z = Z0.clone()
+    _native.check(L.uoc_ms_hill_climb(_native.ptr(X), batch, n, _native.ptr(Z), Z0.shape[1], KAPPA, iters, _native.ptr(ws),
+                                      ws.numel(), _native.stream_ptr(X.device)), "uoc_ms_hill_climb")
+    torch.cuda.synchronize()
+    return Z
+
+
+@pytest.mark.parametrize("batch,n,m", [(1, 224 * 224, 100), (6, 224 * 224, 100), (7, 224 * 224, 100), (8, 224 * 224, 100),
+                                       (11, 224 * 224, 98), (29, 224 * 224, 100), (2, 480 * 640, 100), (3, 37 * 53, 97),
+                                       (300, 16 * 9, 100)])
+def test_seed_tile_parts_are_bit_identical(device, batch, n, m):
+    """The flat item schedule of the hill-climbing kernel (csrc/meanshift.hip, HcPlan) may run left-over virtual blocks as
+    2 / 3 / 6 seed-tile parts on otherwise idle CUs.  A part accumulates its seed tiles over the same pixel tiles in
+    the same order, so the converged seeds must be BIT-identical for every split, forced (UOC_HC_PARTS, speed-only) or
+    chosen by the makespan model (0), whatever the batch (tail only / tail + last round / two passes over the grid)."""
+    from unseenobjectclustering_amd import _native
+    g = torch.Generator(device="cpu").manual_seed(batch * 1000 + m)
+    X = torch.nn.functional.normalize(torch.randn(batch, n, 64, generator=g), dim=-1).to(device)
+    Z0 = torch.nn.functional.normalize(torch.randn(batch, m, 64, generator=g), dim=-1).to(device)
+    old = os.environ.get("UOC_HC_PARTS")
+    try:
+        out = {}
+        for parts in (1, 0, 2, 3, 6):
+            os.environ["UOC_HC_PARTS"] = str(parts)
+            _native.lib().uoc_reload_env()
+            out[parts] = _hill_climb_raw(X, Z0, iters=3)
+        for parts in (0, 2, 3, 6):
+            assert torch.equal(out[parts], out[1]), f"{parts} seed-tile parts differ from whole items"
+        assert torch.isfinite(out[1]).all() and not torch.equal(out[1], Z0)
+    finally:
+        os.environ.pop("UOC_HC_PARTS", None)
+        if old is not None:
+            os.environ["UOC_HC_PARTS"] = old
+        _native.lib().uoc_reload_env()
+
+
 def test_full_size_properties(device):
     """480x640 (BASELINE config 3): determinism, purity against the generating partition,
     label 0 is the largest cluster, seed indices distinct and in range."""

@@ -85,7 +85,7 @@ def test_shipped_library_has_no_result_affecting_knobs():
     blob = open(LIB_PATH, "rb").read()
     names = set(m.decode() for m in re.findall(rb"UOC_[A-Z0-9_]{3,}\x00", blob))
     names = {n.rstrip("\x00") for n in names}
-    assert names <= {"UOC_CONV_AUTOTUNE", "UOC_CONV_TUNE_CACHE", "UOC_CONV_VERBOSE", "UOC_FPS_PERSISTENT", "UOC_SPLIT_MAX_MB"}, names
+    assert names <= {"UOC_CONV_AUTOTUNE", "UOC_CONV_TUNE_CACHE", "UOC_CONV_VERBOSE", "UOC_FPS_PERSISTENT", "UOC_SPLIT_MAX_MB", "UOC_HC_PARTS"}, names
     fp = _native.config_fingerprint()
     assert fp != 0
     old = {k: os.environ.get(k) for k in ("UOC_WINOGRAD_F", "UOC_HC_QUAD", "UOC_WINOGRAD_MIN_CIN")}

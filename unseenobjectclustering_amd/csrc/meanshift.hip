@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include <mutex>
+#include <type_traits>
 #include <utility>
 
 namespace uoc {
@@ -627,8 +628,8 @@ constexpr int EXP_STEPS = 7;
 //      three single VALU steps of the exp() of tile i-1, elements round-robin so no VALU waits on the one before it
 //      (a VALU behind an independent MFMA costs ~1.7 cycles of issue, same microbenchmark: 35.3).
 // sched_barrier(0) after every slot keeps hipcc from regrouping.
-// ABL (timing ablations, dev only; results are wrong for ABL != 0): 1 = no exp arithmetic, 4 = S chains only,
-// 5 = accumulate MFMAs only.
+// FIRST: the item's first pixel tile starts every accumulator from the inline constant 0 instead of reading it — the
+// accumulators are never zeroed (hipcc placed 2 x 112 v_accvgpr_write at the head of every item: 2 us per item).
 //
 // QUAD: the last seed tile holds at most 4 seeds (m = 100 = 6 x 16 + 4) and runs on v_mfma_f32_4x4x1_16B_f32 — sixteen
 // independent 4x4 outer products per instruction, an eighth of the 16x16x4 instruction's time — instead of a padded
@@ -639,12 +640,12 @@ constexpr int EXP_STEPS = 7;
 //   The result has the layout of a regular tile's S (reg r <-> pixel 4q+r) with seed t%4 in place of seed t, so exp()
 //   and the accumulate step keep their code: acc[last][ct] += W[pixel 4q+r][seed i] X[pixel 4q+r][chan 4t+ct] with
 //   block = (channel group t/4, pixel group q), summed over the four pixel groups once per virtual block.
-template <int ST, int ABL, bool QUAD, int I>
+template <int ST, bool FIRST, bool QUAD, int I>
 __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&xc)[4],
                                          const float4 (&zb)[ST][4], f32x4 (&acc)[ST][4], f32x4 (&Sv)[ST + 2],
                                          float (&wv)[ST + 2][4], ExpState (&es)[4], float kappa) {
   // Sv / wv carry two spare rows so that the (never executed) I-1 / I-2 references of the first steps stay in range
-  constexpr bool do_s = I < ST && ABL != 5, do_a = I >= 2 && ABL != 4, do_e = I >= 1 && I - 1 < ST;
+  constexpr bool do_s = I < ST, do_a = I >= 2, do_e = I >= 1 && I - 1 < ST;
   constexpr int IS = I < ST ? I : 0, IE = I >= 1 ? I - 1 : 0, IA = I >= 2 ? I - 2 : 0;
   constexpr bool quad_s = QUAD && IS == ST - 1, quad_a = QUAD && IA == ST - 1;
   if (do_s) {
@@ -658,6 +659,10 @@ __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&x
         Sv[IS] = mfma4(f4c(xa[v], e), f4c(zb[IS][v], e), Sv[IS]);
       __builtin_amdgcn_sched_barrier(0);
     }
+    // The finished S tile is wanted in VGPRs (exp is VALU).  Saying so keeps hipcc from parking S chains in the AGPRs that
+    // hold loop-carried accumulators and moving those out of the way and back (24 v_accvgpr_mov per pixel tile in the
+    // flat-schedule kernel; every VALU instruction costs matrix-pipe time here).
+    asm volatile("" : "+v"(Sv[IS]));
     if (quad_s) {   // the four channel phases (lanes t, t+4, t+8, t+12 of a row): identical sum order on every lane
 #pragma unroll
       for (int r = 0; r < 4; ++r) Sv[IS][r] += dpp_f<0x128>(Sv[IS][r]);   // row_ror:8
@@ -671,10 +676,11 @@ __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&x
   for (int k = 0; k < 16; ++k) {
     if (do_a) {
       const int r = k >> 2, ct = k & 3;
+      const f32x4 c0 = (FIRST && r == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[IA][ct];   // k = ct: the accumulator's first MFMA
       if (quad_a)
-        acc[IA][ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[IA][r], f4c(xb[r], ct), acc[IA][ct], 0, 0, 0);
+        acc[IA][ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[IA][r], f4c(xb[r], ct), c0, 0, 0, 0);
       else
-        acc[IA][ct] = mfma4(wv[IA][r], f4c(xb[r], ct), acc[IA][ct]);
+        acc[IA][ct] = mfma4(wv[IA][r], f4c(xb[r], ct), c0);
     }
     // the VALU steps that belong behind this slot, in 4 clusters per seed tile (behind MFMAs 3, 7, 11, 15): every
     // MFMA -> VALU switch costs ~2.7 cycles on top of the VALU's own 2 (scripts/mfma_shadow.hip)
@@ -684,163 +690,192 @@ __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&x
       const int o = o0 + j;
       if (o >= o1) continue;
       const int step = o >> 2, r = o & 3;   // step-major, element-minor: consecutive ops are independent
-      if (ABL == 1 || ABL == 5) {
-        if (step == 0) wv[IE][r] = ABL == 5 ? f4c(xa[r], I & 3) : kappa * Sv[IE][r];
-      } else if (ABL == 4) {
-        if (step == 0) acc[IE][r] += Sv[IE];
-      } else {
-        switch (step) {
-          case 0: exp_step<0>(es[r], Sv[IE][r], kappa, wv[IE][r]); break;
-          case 1: exp_step<1>(es[r], 0.f, kappa, wv[IE][r]); break;
-          case 2: exp_step<2>(es[r], 0.f, kappa, wv[IE][r]); break;
-          case 3: exp_step<3>(es[r], 0.f, kappa, wv[IE][r]); break;
-          case 4: exp_step<4>(es[r], 0.f, kappa, wv[IE][r]); break;
-          case 5: exp_step<5>(es[r], 0.f, kappa, wv[IE][r]); break;
-          default: exp_step<6>(es[r], 0.f, kappa, wv[IE][r]); break;
-        }
+      switch (step) {
+        case 0: exp_step<0>(es[r], Sv[IE][r], kappa, wv[IE][r]); break;
+        case 1: exp_step<1>(es[r], 0.f, kappa, wv[IE][r]); break;
+        case 2: exp_step<2>(es[r], 0.f, kappa, wv[IE][r]); break;
+        case 3: exp_step<3>(es[r], 0.f, kappa, wv[IE][r]); break;
+        case 4: exp_step<4>(es[r], 0.f, kappa, wv[IE][r]); break;
+        case 5: exp_step<5>(es[r], 0.f, kappa, wv[IE][r]); break;
+        default: exp_step<6>(es[r], 0.f, kappa, wv[IE][r]); break;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
-template <int ST, int ABL, bool QUAD, int... Is>
+template <int ST, bool FIRST, bool QUAD, int... Is>
 __device__ __forceinline__ void hcr_tile_steps(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&xc)[4],
                                                const float4 (&zb)[ST][4], f32x4 (&acc)[ST][4], float kappa,
                                                std::integer_sequence<int, Is...>) {
   f32x4 Sv[ST + 2];
   float wv[ST + 2][4];
   ExpState es[4];
-  (hcr_step<ST, ABL, QUAD, Is>(xa, xb, xc, zb, acc, Sv, wv, es, kappa), ...);
+  (hcr_step<ST, FIRST, QUAD, Is>(xa, xb, xc, zb, acc, Sv, wv, es, kappa), ...);
 }
 
-template <int ST, int ABL, bool QUAD>
+template <int ST, bool FIRST, bool QUAD>
 __device__ __forceinline__ void hcr_tile(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&xc)[4],
                                          const float4 (&zb)[ST][4], f32x4 (&acc)[ST][4], float kappa) {
-  hcr_tile_steps<ST, ABL, QUAD>(xa, xb, xc, zb, acc, kappa, std::make_integer_sequence<int, ST + 2>{});
+  hcr_tile_steps<ST, FIRST, QUAD>(xa, xb, xc, zb, acc, kappa, std::make_integer_sequence<int, ST + 2>{});
 }
 
-// THE SHIPPED KERNEL (UOC_HC_VARIANT=2, default): one wave per SIMD (4 waves per block, one block per CU), every wave
-// all ST seed tiles (~330 of its 512 registers), X read exactly once.  Cost model that fits the measurements: a pixel
-// tile costs 32 cycles per MFMA (224) + 2 per VALU (~230) + 8 per v_exp (28) + ~2.7 per MFMA->VALU switch, i.e. the
-// floor of this formulation is ~8 000 cycles per tile against 7 168 of pure MFMA.
-// The 112 KB of LDS serve the cross-wave reductions only.
+// THE SHIPPED KERNEL: one wave per SIMD (4 waves per block, one block per CU), every wave all ST seed tiles (~330 of
+// its 512 registers), X read exactly once.  Cost model that fits the measurements: a pixel tile costs 32 cycles per MFMA
+// (224) + 2 per VALU (~230) + 8 per v_exp (28) + ~2.7 per MFMA->VALU switch, i.e. the floor of this formulation is
+// ~8 000 cycles per tile against 7 168 of pure MFMA.  The 112 KB of LDS serve the cross-wave reductions only.
 //
-// VIRTUAL blocks: the field is always cut into nvb blocks of 4 waves (nvb depends on n only, hc_virtual_blocks), and the
-// launch's physical blocks walk them.  Which pixel tiles meet in which partial sum, and the order of every fp32
-// addition, therefore do not depend on how many fields share the launch (batch), on the CU count or on the grid.
-// The walk is ONE software pipeline: the seed fragments are loaded once, and the first tile of the next virtual block
-// is already in flight while the current one is reduced through LDS and stored (per virtual block that leaves the
-// reduction itself, ~2 us against ~70 us of tiles).
+// VIRTUAL blocks: a field is always cut into nvb blocks of 4 waves (nvb depends on n only, hc_virtual_blocks).  Which
+// pixel tiles meet in which partial sum, and the order of every fp32 addition, therefore do not depend on how many
+// fields share the launch (batch), on the CU count or on the grid.
+//
+// FLAT ITEM SCHEDULE (round 6).  The launch's batch x nvb virtual blocks form ONE list that a 1-D grid of at most one
+// block per CU works through (HcPlan):
+//   * items [0, n1) run whole, a block staying inside one field where the counts allow it, else taking items g, g + grid,
+//     ... (when the field changes the seed fragments are reloaded under the previous item's reduction);
+//   * the TAIL items [n1, items) — what is left after the full rounds — run as `parts` SEED-TILE parts each (7 seed tiles
+//     = 3 + 4, 2 + 2 + 3 or 5 x 1 + 2, the 4-seed tile riding with the last part).  A part walks the virtual block's pixel tiles exactly as the whole
+//     item would and accumulates ITS seed tiles only: every accumulator sees the same MFMAs in the same order, so the
+//     partial sums are bit-identical whatever the split (tests/test_meanshift_gpu.py), while 87 left-over virtual blocks
+//     (7 crops = 343 on 256 CUs) occupy 174 CUs for 4/7 of a round instead of 87 CUs for a whole one.  Parts are listed
+//     largest first and dealt out forwards, then backwards (two passes at most): with sorted items that IS the
+//     longest-processing-time rule.  The price is reading the tail's pixels `parts` times (from L2).
+// The plan is a pure function of (batch, nvb, CU count) evaluated on the host by makespan (hc_make_plan).
+// The walk is ONE software pipeline: the first pixel tile of the next item is already in flight while the current one is
+// reduced through LDS and stored (per item that leaves the reduction itself, ~2 us against ~56 us of tiles).
 // (Round 2's two-waves-per-SIMD variant with the seeds split between the waves measured the same 87.5 vs 88.0 us and
 // fetched X twice; it was removed in round 3 — fp32 MFMA and VALU share the SIMD's lanes, DESIGN.md.)
-template <int ST, int ABL = 0, bool QUAD = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void hc_iter_reg1_kernel(
-    const float *__restrict__ X, int n, const float *__restrict__ Z, int m, float kappa, float *__restrict__ partial,
-    int nvb) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int b = blockIdx.y;
-  X += (size_t)b * n * C;
-  Z += (size_t)b * m * C;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t = lane & 15, q = lane >> 4;
-  f32x4 *red = reinterpret_cast<f32x4 *>(smem);  // [4 waves][ST*4][64] f32x4
-  f32x4 *red_wave = red + (size_t)wave * ST * 4 * 64;
-
-  // seed fragments: zb[i][v] = Z[seed 16i+t][16v+4q .. +3]  (B operand of S^T = X Z^T), zero rows beyond m.
-  // Unconditional loads from a clamped row + a select later: a predicated load would get its own branch and its own
-  // s_waitcnt vmcnt(0), i.e. ST serialised memory latencies in the prologue.
-  float4 zb[ST][4];
+struct HcPlan {
+  int nvb;     // virtual blocks per field
+  int items;   // batch * nvb
+  int n1;      // items [0, n1) run whole
+  int parts;   // every item in [n1, items) runs as this many seed-tile parts (1: n1 == items)
+  int grid;    // physical blocks
+};
+struct HcGeom {
+  const float *X;   // [batch][n][64]
+  int n, ntile, stride;
+  int lane, wave, t, q;
+};
+// Pixel tiles: branch-free loads (clamped row index).  A clamped xa row only produces a finite S / W for a pixel
+// whose xb row is zeroed, so out-of-range pixels contribute exactly 0; xb is zeroed only in the (rare) partial tile.
+// Rows are addressed from the launch's base X by a 32-bit GLOBAL pixel index (field b starts at row b * n; batch * n
+// rows of 256 bytes always fit: 2^31 rows would be 550 GB), so the field of a tile is a scalar offset, not a pointer.
+template <bool KQ>
+__device__ __forceinline__ void hc_load_tile(const HcGeom &ge, int b, int tl, float4 (&a)[4], float4 (&bb)[4],
+                                             float4 (&cc)[4]) {
+  const int row0 = b * ge.n;
+  const int base = row0 + min(tl, ge.ntile - 1) * 16, last = row0 + ge.n - 1;
+  const float *__restrict__ X = ge.X;
+  const int pa = min(base + ge.t, last);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) a[v] = *reinterpret_cast<const float4 *>(X + (size_t)(unsigned)pa * C + 16 * v + 4 * ge.q);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int pb = min(base + 4 * ge.q + r, last);
+    bb[r] = *reinterpret_cast<const float4 *>(X + (size_t)(unsigned)pb * C + 4 * ge.t);
+  }
+  if (KQ) {   // third view of the tile for the 4x4x1 S step: pixel 4q + t%4, channels 16(t/4) + 4v .. +3
+    const int pc = min(base + 4 * ge.q + (ge.t & 3), last);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) cc[v] = *reinterpret_cast<const float4 *>(X + (size_t)(unsigned)pc * C + 16 * (ge.t >> 2) + 4 * v);
+  }
+}
+// applied when the tile becomes the current one (a select on freshly loaded data would force a wait at the load)
+__device__ __forceinline__ void hc_mask_tile(const HcGeom &ge, int tl, float4 (&bb)[4]) {
+  const int base = min(tl, ge.ntile - 1) * 16;
+  if (base + 16 > ge.n) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (base + 4 * ge.q + r >= ge.n) bb[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+// seed fragments of ST tiles starting at row 0 of Zs (m rows are valid): zb[i][v] = Zs[seed 16i+t][16v+4q .. +3]
+// (B operand of S^T = X Z^T), zero rows beyond m.  Unconditional loads from a clamped row + a select: a predicated
+// load would get its own branch and its own s_waitcnt vmcnt(0), i.e. ST serialised memory latencies.
+template <int ST, bool QUAD>
+__device__ __forceinline__ void hc_seed_loads(const HcGeom &ge, const float *__restrict__ Zs, int m, float4 (&zb)[ST][4]) {
+  const int t = ge.t, q = ge.q;
 #pragma unroll
   for (int i = 0; i < ST; ++i)
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       if (QUAD && i == ST - 1)   // the 4x4x1 tile: seed 16(ST-1) + t%4, channels 16(t/4) + 4v .. +3
-        zb[i][v] = *reinterpret_cast<const float4 *>(Z + (size_t)min(16 * i + (t & 3), m - 1) * C + 16 * (t >> 2) + 4 * v);
+        zb[i][v] = *reinterpret_cast<const float4 *>(Zs + (size_t)min(16 * i + (t & 3), m - 1) * C + 16 * (t >> 2) + 4 * v);
       else
-        zb[i][v] = *reinterpret_cast<const float4 *>(Z + (size_t)min(16 * i + t, m - 1) * C + 16 * v + 4 * q);
+        zb[i][v] = *reinterpret_cast<const float4 *>(Zs + (size_t)min(16 * i + t, m - 1) * C + 16 * v + 4 * q);
     }
-  f32x4 acc[ST][4];
+}
+// Rows beyond m can only sit in the LAST of the ST tiles (ST = ceil(m / 16) for a whole item; a part either ends with the
+// launch's last tile or holds full tiles only).
+template <int ST, bool QUAD>
+__device__ __forceinline__ void hc_seed_mask(const HcGeom &ge, int m, float4 (&zb)[ST][4]) {
+  const bool beyond = 16 * (ST - 1) + (QUAD ? (ge.t & 3) : ge.t) >= m;
 #pragma unroll
-  for (int s = 0; s < ST; ++s)
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) acc[s][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int v = 0; v < 4; ++v) {
+    zb[ST - 1][v].x = beyond ? 0.f : zb[ST - 1][v].x;
+    zb[ST - 1][v].y = beyond ? 0.f : zb[ST - 1][v].y;
+    zb[ST - 1][v].z = beyond ? 0.f : zb[ST - 1][v].z;
+    zb[ST - 1][v].w = beyond ? 0.f : zb[ST - 1][v].w;
+  }
+}
 
-  const int ntile = (n + 15) >> 4;
-  const int stride = nvb * 4;
-  // Pixel tiles: branch-free loads (clamped row index).  A clamped xa row only produces a finite S / W for a pixel
-  // whose xb row is zeroed, so out-of-range pixels contribute exactly 0; xb is zeroed only in the (rare) partial tile.
-  auto load_tile = [&](int tl, float4(&a)[4], float4(&bb)[4], float4(&cc)[4]) {
-    const int base = min(tl, ntile - 1) * 16;
-    const int pa = min(base + t, n - 1);
+// ONE item: the pixel tiles of virtual block vb of field b against the ST seed tiles whose fragments are in zb; the
+// partial sums go to dst (row 0 = the first of these seeds, 64 floats per row).  xa / xb / xc hold the item's first
+// tile on entry and the first tile of the NEXT item (field nb, tile nt) on exit.  Znext != nullptr: the next item belongs
+// to another field — its seed fragments are requested as soon as the last pixel tile is done and arrive under the
+// cross-wave reduction.
+template <int ST, bool QUAD, bool KQ>
+__device__ __forceinline__ void hc_item(const HcGeom &ge, float4 (&zb)[ST][4], float kappa, int b, int vb, int nb,
+                                        int nt, float4 (&xa)[4], float4 (&xb)[4], float4 (&xc)[4], int &held_b,
+                                        int &held_t, f32x4 (&acc)[ST][4], f32x4 *red, float *__restrict__ dst,
+                                        const float *__restrict__ Znext, int m) {
+  // acc: written by the item's first tile, no value on entry
+  const int lane = ge.lane, wave = ge.wave, t = ge.t, q = ge.q;
+  f32x4 *red_wave = red + (size_t)wave * ST * 4 * 64;
+  // The loads of the wave's NEXT tile (the first tile of the next item behind the last one of this item) are issued
+  // before the current tile's MFMAs and first read after them.  hipcc undoes a plain `xa = na` double buffer (it
+  // coalesces the copy, rotates the loop and ends up with load-then-wait at the top of every tile, ~0.8 us exposed per
+  // tile) and sinks the loads of a two-body ping-pong loop into the second body — so the hand-over is 32 opaque v_mov
+  // and a sched_barrier keeps the loads above the first MFMA.
+  auto one_tile = [&](int tile, auto first) {   // invariant: (held_b, held_t) == (b, tile)
+    const bool more = tile + ge.stride < ge.ntile;
+    const int nxt = more ? tile + ge.stride : nt;
+    float4 na[4], nbv[4], nc[4];
+    hc_load_tile<KQ>(ge, more ? b : nb, nxt, na, nbv, nc);
+    __builtin_amdgcn_sched_barrier(0);
+    hcr_tile<ST, decltype(first)::value, QUAD>(xa, xb, xc, zb, acc, kappa);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) a[v] = *reinterpret_cast<const float4 *>(X + (size_t)pa * C + 16 * v + 4 * q);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int pb = base + 4 * q + r;
-      bb[r] = *reinterpret_cast<const float4 *>(X + (size_t)min(pb, n - 1) * C + 4 * t);
+    for (int v = 0; v < 4; ++v) {
+      asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                   : "=&v"(xa[v].x), "=&v"(xa[v].y), "=&v"(xa[v].z), "=&v"(xa[v].w)
+                   : "v"(na[v].x), "v"(na[v].y), "v"(na[v].z), "v"(na[v].w));
+      asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                   : "=&v"(xb[v].x), "=&v"(xb[v].y), "=&v"(xb[v].z), "=&v"(xb[v].w)
+                   : "v"(nbv[v].x), "v"(nbv[v].y), "v"(nbv[v].z), "v"(nbv[v].w));
     }
-    if (QUAD) {   // third view of the tile for the 4x4x1 S step: pixel 4q + t%4, channels 16(t/4) + 4v .. +3
-      const int pc = min(base + 4 * q + (t & 3), n - 1);
+    if (KQ) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) cc[v] = *reinterpret_cast<const float4 *>(X + (size_t)pc * C + 16 * (t >> 2) + 4 * v);
-    }
-  };
-  // applied when the tile becomes the current one (a select on freshly loaded data would force a wait at the load)
-  auto mask_tile = [&](int tl, float4(&bb)[4]) {
-    const int base = min(tl, ntile - 1) * 16;
-    if (base + 16 > n) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (base + 4 * q + r >= n) bb[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  int vb = blockIdx.x;
-  int held = vb * 4 + wave;   // the tile whose pixels sit in xa / xb
-  float4 xa[4], xb[4], xc[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) xc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  load_tile(held, xa, xb, xc);
-  mask_tile(held, xb);
-#pragma unroll
-  for (int i = 0; i < ST; ++i)
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-      if (16 * i + ((QUAD && i == ST - 1) ? (t & 3) : t) >= m) zb[i][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  while (vb < nvb) {
-    // The loads of the wave's NEXT tile (the first tile of the next virtual block behind the last one of this block)
-    // are issued before the current tile's MFMAs and first read after them.  hipcc undoes a plain `xa = na` double
-    // buffer (it coalesces the copy, rotates the loop and ends up with load-then-wait at the top of every tile, ~0.8 us
-    // exposed per tile) and sinks the loads of a two-body ping-pong loop into the second body — so the hand-over is 32
-    // opaque v_mov and a sched_barrier keeps the loads above the first MFMA.
-    for (int tile = vb * 4 + wave; tile < ntile; tile += stride) {   // invariant: held == tile
-      const int nxt = tile + stride < ntile ? tile + stride : (vb + (int)gridDim.x) * 4 + wave;
-      float4 na[4], nb[4], nc[4];
-      load_tile(nxt, na, nb, nc);
-      __builtin_amdgcn_sched_barrier(0);
-      hcr_tile<ST, ABL, QUAD>(xa, xb, xc, zb, acc, kappa);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
+      for (int v = 0; v < 4; ++v)
         asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                     : "=&v"(xa[v].x), "=&v"(xa[v].y), "=&v"(xa[v].z), "=&v"(xa[v].w)
-                     : "v"(na[v].x), "v"(na[v].y), "v"(na[v].z), "v"(na[v].w));
-        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                     : "=&v"(xb[v].x), "=&v"(xb[v].y), "=&v"(xb[v].z), "=&v"(xb[v].w)
-                     : "v"(nb[v].x), "v"(nb[v].y), "v"(nb[v].z), "v"(nb[v].w));
-      }
-      if (QUAD) {
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                       : "=&v"(xc[v].x), "=&v"(xc[v].y), "=&v"(xc[v].z), "=&v"(xc[v].w)
-                       : "v"(nc[v].x), "v"(nc[v].y), "v"(nc[v].z), "v"(nc[v].w));
-      }
-      mask_tile(nxt, xb);
-      held = nxt;
+                     : "=&v"(xc[v].x), "=&v"(xc[v].y), "=&v"(xc[v].z), "=&v"(xc[v].w)
+                     : "v"(nc[v].x), "v"(nc[v].y), "v"(nc[v].z), "v"(nc[v].w));
     }
-    // ---- this virtual block is complete: the four waves' accumulators meet in LDS, (w0 + w1) + (w2 + w3) ----
+    hc_mask_tile(ge, nxt, xb);
+    held_b = more ? b : nb;
+    held_t = nxt;
+  };
+  // The first tile's accumulate MFMAs start from the constant 0 (hcr_step, FIRST): the accumulators are never zeroed.
+  // A wave without any tile (tiny fields) hands zeros to the reduction instead of its (undefined) accumulators.
+  int tile = vb * 4 + wave;
+  const bool has_tile = tile < ge.ntile;
+  if (has_tile) {
+    one_tile(tile, std::true_type{});
+    for (tile += ge.stride; tile < ge.ntile; tile += ge.stride) one_tile(tile, std::false_type{});
+  }
+  if (Znext) hc_seed_loads<ST, QUAD>(ge, Znext, m, zb);
+  // ---- the item is complete: the four waves' accumulators meet in LDS, (w0 + w1) + (w2 + w3) ----
+  if (has_tile) {
     if (QUAD) {   // the 4x4x1 tile's accumulators are partial over the pixel groups q: lanes l, l^16, l^32, l^48 -> (q0+q1)+(q2+q3)
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct)
@@ -855,34 +890,134 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int s = 0; s < ST; ++s)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        red_wave[(s * 4 + ct) * 64 + lane] = acc[s][ct];
-        acc[s][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    __syncthreads();
-    float *dst = partial + ((size_t)b * nvb + vb) * (ST * 16) * C;
-    for (int s = wave; s < ST; s += 4) {
-      f32x4 o[4];
+      for (int ct = 0; ct < 4; ++ct) red_wave[(s * 4 + ct) * 64 + lane] = acc[s][ct];
+  } else {
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct) {
-        const f32x4 a0 = red[((0 * ST + s) * 4 + ct) * 64 + lane], a1 = red[((1 * ST + s) * 4 + ct) * 64 + lane];
-        const f32x4 a2 = red[((2 * ST + s) * 4 + ct) * 64 + lane], a3 = red[((3 * ST + s) * 4 + ct) * 64 + lane];
-        o[ct] = (a0 + a1) + (a2 + a3);
-      }
-      // lane (t,q) reg r holds newZ[seed 16s+4q+r][channel 4t+ct]
+    for (int s = 0; s < ST; ++s)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<float4 *>(dst + (size_t)(16 * s + 4 * q + r) * C + 4 * t) =
-            make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+      for (int ct = 0; ct < 4; ++ct) red_wave[(s * 4 + ct) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  for (int s = wave; s < ST; s += 4) {
+    f32x4 a[4][4], o[4];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) a[ct][w] = red[((w * ST + s) * 4 + ct) * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);   // all 16 reads in flight before the first add (hipcc paired each read with its wait)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) o[ct] = (a[ct][0] + a[ct][1]) + (a[ct][2] + a[ct][3]);
+    // lane (t,q) reg r holds newZ[seed 16s+4q+r][channel 4t+ct]
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<float4 *>(dst + (size_t)(16 * s + 4 * q + r) * C + 4 * t) =
+          make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+  }
+  __syncthreads();  // the reduction buffer is written again by the next item
+  if (Znext) hc_seed_mask<ST, QUAD>(ge, m, zb);
+}
+
+// A tail part: seed tiles [s0, s0 + ST) of the launch's tiles, with its own fragments and its own first pixel tile (no
+// hand-over of registers between the bodies: hipcc then keeps the whole-item loop's live ranges to itself — with the
+// next item's pixels carried across the bodies it parked them in AGPRs and paid 66 extra VALU moves per pixel tile).
+template <int ST, bool QUAD>
+__device__ __forceinline__ void hc_part(const HcGeom &ge, const float *__restrict__ Zb, int m, int s0, float kappa, int b,
+                                        int vb, f32x4 *red, float *__restrict__ dst_item) {
+  float4 zb[ST][4];
+  hc_seed_loads<ST, QUAD>(ge, Zb + (size_t)16 * s0 * C, m - 16 * s0, zb);
+  float4 xa[4], xb[4], xc[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) xc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int held_b = b, held_t = vb * 4 + ge.wave;
+  hc_load_tile<QUAD>(ge, b, held_t, xa, xb, xc);
+  hc_seed_mask<ST, QUAD>(ge, m - 16 * s0, zb);
+  hc_mask_tile(ge, held_t, xb);
+  f32x4 acc[ST][4];
+  hc_item<ST, QUAD, QUAD>(ge, zb, kappa, b, vb, b, held_t, xa, xb, xc, held_b, held_t, acc, red,
+                          dst_item + (size_t)16 * s0 * C, nullptr, 0);
+}
+
+template <int ST, bool QUAD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void hc_iter_flat_kernel(
+    const float *__restrict__ X, int n, const float *__restrict__ Z, int m, float kappa, float *__restrict__ partial,
+    HcPlan plan) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4 *red = reinterpret_cast<f32x4 *>(smem);  // [4 waves][ST*4][64] f32x4
+  const int tid = threadIdx.x;
+  HcGeom ge;
+  ge.X = X;
+  ge.n = n;
+  ge.ntile = (n + 15) >> 4;
+  ge.stride = plan.nvb * 4;
+  ge.lane = tid & 63;
+  ge.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  ge.t = ge.lane & 15;
+  ge.q = ge.lane >> 4;
+  const int g = blockIdx.x;
+  constexpr bool SPLIT = ST == 7 && QUAD;   // the seed-tile parts exist for the 97..100-seed launches (the reference's 100)
+
+  // ---- whole items.  If every block can stay inside ONE field (q items per block, q | nvb, whole fields only) block
+  //      (field f, x) takes the virtual blocks x, x + nvb/q, ...: the pixel tiles of its items then share their pages
+  //      (a wave's tiles are 4 MB apart at 480x640, the next item's 1 MB further on).  Otherwise block g takes items g,
+  //      g + grid, ... (4 x 480x640: 294 us against 286 — every item in another field; still dense across the grid,
+  //      where a contiguous chunk per block had 256 blocks read 4 KB pieces 16 KB apart) ----
+  if (g < plan.n1) {
+    const int q = plan.n1 / plan.grid;
+    const bool affine = q >= 1 && q * plan.grid == plan.n1 && plan.n1 % plan.nvb == 0 && plan.nvb % q == 0;
+    const int per = affine ? plan.nvb / q : 0;                       // blocks per field
+    const int step = affine ? per : plan.grid;                       // item stride of a block
+    const int first = affine ? (g / per) * plan.nvb + g % per : g;   // its first item
+    const int count = affine ? q : (plan.n1 - g + plan.grid - 1) / plan.grid;
+    int b = first / plan.nvb, vb = first % plan.nvb;
+    float4 xa[4], xb[4], xc[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) xc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int held_b = b, held_t = vb * 4 + ge.wave;   // the tile whose pixels sit in xa / xb / xc
+    hc_load_tile<QUAD>(ge, b, held_t, xa, xb, xc);
+    float4 zb[ST][4];
+    hc_seed_loads<ST, QUAD>(ge, Z + (size_t)b * m * C, m, zb);
+    hc_mask_tile(ge, held_t, xb);
+    hc_seed_mask<ST, QUAD>(ge, m, zb);
+    f32x4 acc[ST][4];
+    for (int j = 0; j < count; ++j) {
+      const int item = first + j * step;
+      const int nitem = j + 1 < count ? item + step : item;   // behind the last one: a harmless reload
+      const int nb = nitem / plan.nvb, nvb_ = nitem % plan.nvb;
+      // (only a wave that had no tile in the previous item — tiny fields — does not hold this item's first tile yet)
+      if (held_b != b || held_t != vb * 4 + ge.wave) {
+        held_b = b;
+        held_t = vb * 4 + ge.wave;
+        hc_load_tile<QUAD>(ge, b, held_t, xa, xb, xc);
+        hc_mask_tile(ge, held_t, xb);
+      }
+      hc_item<ST, QUAD, QUAD>(ge, zb, kappa, b, vb, nb, nvb_ * 4 + ge.wave, xa, xb, xc, held_b, held_t, acc, red,
+                              partial + ((size_t)b * plan.nvb + vb) * (ST * 16) * C,
+                              nb != b ? Z + (size_t)nb * m * C : nullptr, m);
+      b = nb;
+      vb = nvb_;
     }
-    __syncthreads();  // the reduction buffer is written again by the next virtual block
-    vb += gridDim.x;
-    const int first = vb * 4 + wave;
-    // (only a wave that had no tile in the finished block — tiny fields — does not hold the next block's first tile yet)
-    if (held != first) {
-      held = first;
-      load_tile(held, xa, xb, xc);
-      mask_tile(held, xb);
+  }
+  // ---- tail items as seed-tile parts: largest parts first, dealt forwards, then backwards ----
+  if constexpr (SPLIT) {
+    const int R = plan.items - plan.n1, T = R * plan.parts;
+    for (int k = 0; k < 2; ++k) {
+      const int tpos = k * plan.grid + ((k & 1) ? plan.grid - 1 - g : g);
+      if (tpos >= T) break;
+      const int p = tpos / R, item = plan.n1 + tpos % R;
+      const int b = item / plan.nvb, vb = item % plan.nvb;
+      const float *Zb = Z + (size_t)b * m * C;
+      float *dst = partial + ((size_t)b * plan.nvb + vb) * (ST * 16) * C;
+#define UOC_HC_PART(SUB, Q4, S0) hc_part<SUB, Q4>(ge, Zb, m, S0, kappa, b, vb, red, dst)
+      // seed tiles 0..5 are full, tile 6 holds the last <= 4 seeds (a tenth of a full tile's time): balanced splits
+      const int P = plan.parts;
+      if (P == 2) {                                   // {0 1 2} {3 4 5 6}
+        if (p == 0) UOC_HC_PART(4, true, 3); else UOC_HC_PART(3, false, 0);
+      } else if (P == 3) {                            // {0 1} {2 3} {4 5 6}
+        if (p == 0) UOC_HC_PART(3, true, 4); else UOC_HC_PART(2, false, 2 * (p - 1));
+      } else {                                        // 6: {0} {1} {2} {3} {4} {5 6}
+        if (p == 0) UOC_HC_PART(2, true, 5); else UOC_HC_PART(1, false, p - 1);
+      }
+#undef UOC_HC_PART
     }
   }
 }
@@ -1399,6 +1534,74 @@ static int run_select_seeds_streaming(const float *X, int batch, int n, int m, c
   return UOC_OK;
 }
 
+// ---- the flat item schedule of the register-resident hill-climbing kernel (HcPlan, hc_iter_flat_kernel) ----
+// Relative cost of an item on one CU, in units of one 16-seed tile over the virtual block's pixel tiles (9.25 us at 16
+// pixel tiles per wave), fitted to scripts/hc_parts.py on MI355X (profiles/r06_hc_parts.md).
+constexpr double HC_COST_TILES = 6.1;      // a whole item: six 16-seed tiles + the 4-seed tile (a tenth of a full one)
+constexpr double HC_COST_ITEM = 0.76;      // first item of a block, or any part (own fragments + first pixel tile: 7 us)
+constexpr double HC_COST_NEXT = 0.3;       // every further whole item of a block (pipelined)
+static double hc_part_cost(int P, int p) {   // part p of a P-way split (mirrors the kernel's table: largest first)
+  const double tiles = P == 2 ? (p == 0 ? 3.1 : 3.0) : P == 3 ? (p == 0 ? 2.1 : 2.0) : (p == 0 ? 1.1 : 1.0);
+  return tiles + HC_COST_ITEM;
+}
+// Makespan (relative) of a plan under the kernel's static schedule: contiguous chunks of whole items, then the tail
+// parts largest first, dealt forwards and backwards.
+static double hc_plan_cost(const HcPlan &p) {
+  double phase1 = 0.0;
+  if (p.n1 > 0) {
+    const int c = (p.n1 + p.grid - 1) / p.grid;
+    phase1 = c * HC_COST_TILES + HC_COST_ITEM + (c - 1) * HC_COST_NEXT;
+  }
+  const int R = p.items - p.n1, T = R * p.parts;
+  double tail = 0.0;
+  for (int g = 0; g < p.grid && T > 0; ++g) {
+    double c = 0.0;
+    for (int k = 0; k < 2; ++k) {
+      const int t = k * p.grid + ((k & 1) ? p.grid - 1 - g : g);
+      if (t < T) c += hc_part_cost(p.parts, t / R);
+    }
+    if (c > tail) tail = c;
+  }
+  return phase1 + tail;
+}
+static EnvInt g_hc_parts("UOC_HC_PARTS", 0);   // speed-only (bit-identical): 0 = by makespan, 1 / 2 / 3 / 6 = force
+static HcPlan hc_make_plan(int batch, int nvb, bool splittable) {
+  const int cus = device_num_cu() > 0 ? device_num_cu() : 256;
+  HcPlan whole;
+  whole.nvb = nvb;
+  whole.items = batch * nvb;
+  whole.n1 = whole.items;
+  whole.parts = 1;
+  whole.grid = whole.items < cus ? whole.items : cus;
+  if (!splittable) return whole;
+  const int force = g_hc_parts.get();
+  if (force == 1) return whole;
+  HcPlan best = whole;
+  double best_cost = hc_plan_cost(whole);
+  static const int cand[3] = {2, 3, 6};
+  for (int ci = 0; ci < 3; ++ci) {
+    const int P = cand[ci];
+    if (force > 1 && force != P) continue;
+    const int q = whole.items / cus;
+    for (int back = 0; back <= 1; ++back) {   // the tail alone, or the tail + the last full round
+      if (q - back < 0) break;
+      HcPlan c = whole;
+      c.parts = P;
+      c.n1 = (q - back) * cus;
+      const int T = (c.items - c.n1) * P;
+      if (T == 0) continue;
+      c.grid = c.n1 > 0 ? cus : (T < cus ? T : cus);
+      if (T > 2 * c.grid) continue;
+      const double cost = hc_plan_cost(c);
+      if (force > 1 ? (best.parts != P || cost < best_cost) : cost < 0.985 * best_cost) {
+        best = c;
+        best_cost = cost;
+      }
+    }
+  }
+  return best;
+}
+
 template <int ST, int NH>
 static void launch_hc(const float *X, int batch, int n, float *Z, int m, float kappa, int iters,
                       const MsWorkspace &w, hipStream_t st) {
@@ -1413,16 +1616,24 @@ static void launch_hc(const float *X, int batch, int n, float *Z, int m, float k
   }
   const bool reg = NH == 1 && hc_variant() == 2;   // register-resident kernel, one wave per SIMD
   const size_t lds_reg = (size_t)4 * ST * 4 * 64 * sizeof(f32x4);
+  const int nvb = w.hc_nblk;
+  const int last = m - 16 * (ST - 1);                  // seeds in the last tile
+  const bool quad = ST >= 2 && last >= 1 && last <= 4;   // they run on the 4x4x1 MFMA instead of a padded 16-seed tile
+  HcPlan plan = {};
   if constexpr (NH == 1) {
-    static DeviceOnce attr_reg;
-    if (reg && !attr_reg.done() && lds_reg > 64 * 1024) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hc_iter_reg1_kernel<ST>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
-      attr_reg.mark();
+    if (reg) {
+      plan = hc_make_plan(batch, nvb, ST == 7 && quad);
+      static DeviceOnce attr_reg;
+      if (!attr_reg.done() && lds_reg > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hc_iter_flat_kernel<ST, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hc_iter_flat_kernel<ST, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
+        attr_reg.mark();
+      }
     }
   }
-  const int nvb = w.hc_nblk;
-  const int phys = hc_physical_blocks(batch, nvb, reg ? 1 : 2);
+  const int phys = reg ? plan.grid : hc_physical_blocks(batch, nvb, 2);
   for (int it = 0; it < iters; ++it) {
     {
       // NH = 2 recomputes S for each half of the accumulators: (2 + 1) / 2 of the algorithmic flops per half
@@ -1430,22 +1641,12 @@ static void launch_hc(const float *X, int batch, int n, float *Z, int m, float k
                      4.0 * batch * ((double)n * C * NH + 2.0 * m * C * NH), ProfTag{{n, batch, nvb, phys}});
       if constexpr (NH == 1) {
         if (reg) {
-          const dim3 g(phys, batch), bdim(256);
-          {
-            const int quad_ok = 1;   // the last <= 4 seeds run on the 4x4x1 MFMA instead of a padded 16-seed tile
-            const int last = m - 16 * (ST - 1);      // seeds in the last tile
-            if (quad_ok && ST >= 2 && last >= 1 && last <= 4) {
-              static DeviceOnce attr_q;
-              if (!attr_q.done() && lds_reg > 64 * 1024) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hc_iter_reg1_kernel<ST, 0, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_reg);
-                attr_q.mark();
-              }
-              hipLaunchKernelGGL((hc_iter_reg1_kernel<ST, 0, true>), g, bdim, lds_reg, st, X, n, Z, m, kappa, w.hc_partial, nvb);
-            } else {
-              hipLaunchKernelGGL((hc_iter_reg1_kernel<ST, 0, false>), g, bdim, lds_reg, st, X, n, Z, m, kappa, w.hc_partial, nvb);
-            }
-          }
+          if (quad)
+            hipLaunchKernelGGL((hc_iter_flat_kernel<ST, true>), dim3(plan.grid), dim3(256), lds_reg, st, X, n, Z, m, kappa,
+                               w.hc_partial, plan);
+          else
+            hipLaunchKernelGGL((hc_iter_flat_kernel<ST, false>), dim3(plan.grid), dim3(256), lds_reg, st, X, n, Z, m, kappa,
+                               w.hc_partial, plan);
         }
       }
       if (!reg)
