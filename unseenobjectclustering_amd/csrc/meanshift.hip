@@ -18,7 +18,6 @@
 #include <stdlib.h>
 
 #include <mutex>
-#include <type_traits>
 #include <utility>
 
 namespace uoc {
@@ -628,9 +627,6 @@ constexpr int EXP_STEPS = 7;
 //      three single VALU steps of the exp() of tile i-1, elements round-robin so no VALU waits on the one before it
 //      (a VALU behind an independent MFMA costs ~1.7 cycles of issue, same microbenchmark: 35.3).
 // sched_barrier(0) after every slot keeps hipcc from regrouping.
-// FIRST: the item's first pixel tile starts every accumulator from the inline constant 0 instead of reading it — the
-// accumulators are never zeroed (hipcc placed 2 x 112 v_accvgpr_write at the head of every item: 2 us per item).
-//
 // QUAD: the last seed tile holds at most 4 seeds (m = 100 = 6 x 16 + 4) and runs on v_mfma_f32_4x4x1_16B_f32 — sixteen
 // independent 4x4 outer products per instruction, an eighth of the 16x16x4 instruction's time — instead of a padded
 // 16-seed tile (12 % of the kernel's MFMAs were that padding).  With block = (channel phase t/4, pixel group q):
@@ -640,7 +636,7 @@ constexpr int EXP_STEPS = 7;
 //   The result has the layout of a regular tile's S (reg r <-> pixel 4q+r) with seed t%4 in place of seed t, so exp()
 //   and the accumulate step keep their code: acc[last][ct] += W[pixel 4q+r][seed i] X[pixel 4q+r][chan 4t+ct] with
 //   block = (channel group t/4, pixel group q), summed over the four pixel groups once per virtual block.
-template <int ST, bool FIRST, bool QUAD, int I>
+template <int ST, bool QUAD, int I>
 __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&xc)[4],
                                          const float4 (&zb)[ST][4], f32x4 (&acc)[ST][4], f32x4 (&Sv)[ST + 2],
                                          float (&wv)[ST + 2][4], ExpState (&es)[4], float kappa) {
@@ -676,11 +672,10 @@ __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&x
   for (int k = 0; k < 16; ++k) {
     if (do_a) {
       const int r = k >> 2, ct = k & 3;
-      const f32x4 c0 = (FIRST && r == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[IA][ct];   // k = ct: the accumulator's first MFMA
       if (quad_a)
-        acc[IA][ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[IA][r], f4c(xb[r], ct), c0, 0, 0, 0);
+        acc[IA][ct] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[IA][r], f4c(xb[r], ct), acc[IA][ct], 0, 0, 0);
       else
-        acc[IA][ct] = mfma4(wv[IA][r], f4c(xb[r], ct), c0);
+        acc[IA][ct] = mfma4(wv[IA][r], f4c(xb[r], ct), acc[IA][ct]);
     }
     // the VALU steps that belong behind this slot, in 4 clusters per seed tile (behind MFMAs 3, 7, 11, 15): every
     // MFMA -> VALU switch costs ~2.7 cycles on top of the VALU's own 2 (scripts/mfma_shadow.hip)
@@ -704,20 +699,20 @@ __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&x
   }
 }
 
-template <int ST, bool FIRST, bool QUAD, int... Is>
+template <int ST, bool QUAD, int... Is>
 __device__ __forceinline__ void hcr_tile_steps(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&xc)[4],
                                                const float4 (&zb)[ST][4], f32x4 (&acc)[ST][4], float kappa,
                                                std::integer_sequence<int, Is...>) {
   f32x4 Sv[ST + 2];
   float wv[ST + 2][4];
   ExpState es[4];
-  (hcr_step<ST, FIRST, QUAD, Is>(xa, xb, xc, zb, acc, Sv, wv, es, kappa), ...);
+  (hcr_step<ST, QUAD, Is>(xa, xb, xc, zb, acc, Sv, wv, es, kappa), ...);
 }
 
-template <int ST, bool FIRST, bool QUAD>
+template <int ST, bool QUAD>
 __device__ __forceinline__ void hcr_tile(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&xc)[4],
                                          const float4 (&zb)[ST][4], f32x4 (&acc)[ST][4], float kappa) {
-  hcr_tile_steps<ST, FIRST, QUAD>(xa, xb, xc, zb, acc, kappa, std::make_integer_sequence<int, ST + 2>{});
+  hcr_tile_steps<ST, QUAD>(xa, xb, xc, zb, acc, kappa, std::make_integer_sequence<int, ST + 2>{});
 }
 
 // THE SHIPPED KERNEL: one wave per SIMD (4 waves per block, one block per CU), every wave all ST seed tiles (~330 of
@@ -820,6 +815,18 @@ __device__ __forceinline__ void hc_seed_mask(const HcGeom &ge, int m, float4 (&z
   }
 }
 
+// All-zero accumulators from the matrix pipe (0 x 0 + 0): 28 MFMAs that run while the wave waits at a barrier or for its
+// first pixels.  112 v_accvgpr_write cost VALU issue — hipcc put them (twice) at the head of every item, 2 us per item.
+template <int ST>
+__device__ __forceinline__ void hc_zero_acc(f32x4 (&acc)[ST][4]) {
+  float z = 0.f;
+  asm volatile("" : "+v"(z));   // opaque: mfma(0, 0, 0) must not fold into register writes
+#pragma unroll
+  for (int s = 0; s < ST; ++s)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[s][ct] = mfma4(z, z, f32x4{0.f, 0.f, 0.f, 0.f});
+}
+
 // ONE item: the pixel tiles of virtual block vb of field b against the ST seed tiles whose fragments are in zb; the
 // partial sums go to dst (row 0 = the first of these seeds, 64 floats per row).  xa / xb / xc hold the item's first
 // tile on entry and the first tile of the NEXT item (field nb, tile nt) on exit.  Znext != nullptr: the next item belongs
@@ -830,7 +837,7 @@ __device__ __forceinline__ void hc_item(const HcGeom &ge, float4 (&zb)[ST][4], f
                                         int nt, float4 (&xa)[4], float4 (&xb)[4], float4 (&xc)[4], int &held_b,
                                         int &held_t, f32x4 (&acc)[ST][4], f32x4 *red, float *__restrict__ dst,
                                         const float *__restrict__ Znext, int m) {
-  // acc: written by the item's first tile, no value on entry
+  // acc: all zero on entry, all zero again on exit
   const int lane = ge.lane, wave = ge.wave, t = ge.t, q = ge.q;
   f32x4 *red_wave = red + (size_t)wave * ST * 4 * 64;
   // The loads of the wave's NEXT tile (the first tile of the next item behind the last one of this item) are issued
@@ -838,13 +845,13 @@ __device__ __forceinline__ void hc_item(const HcGeom &ge, float4 (&zb)[ST][4], f
   // coalesces the copy, rotates the loop and ends up with load-then-wait at the top of every tile, ~0.8 us exposed per
   // tile) and sinks the loads of a two-body ping-pong loop into the second body — so the hand-over is 32 opaque v_mov
   // and a sched_barrier keeps the loads above the first MFMA.
-  auto one_tile = [&](int tile, auto first) {   // invariant: (held_b, held_t) == (b, tile)
+  auto one_tile = [&](int tile) {   // invariant: (held_b, held_t) == (b, tile)
     const bool more = tile + ge.stride < ge.ntile;
     const int nxt = more ? tile + ge.stride : nt;
     float4 na[4], nbv[4], nc[4];
     hc_load_tile<KQ>(ge, more ? b : nb, nxt, na, nbv, nc);
     __builtin_amdgcn_sched_barrier(0);
-    hcr_tile<ST, decltype(first)::value, QUAD>(xa, xb, xc, zb, acc, kappa);
+    hcr_tile<ST, QUAD>(xa, xb, xc, zb, acc, kappa);
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
       asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
@@ -865,38 +872,25 @@ __device__ __forceinline__ void hc_item(const HcGeom &ge, float4 (&zb)[ST][4], f
     held_b = more ? b : nb;
     held_t = nxt;
   };
-  // The first tile's accumulate MFMAs start from the constant 0 (hcr_step, FIRST): the accumulators are never zeroed.
-  // A wave without any tile (tiny fields) hands zeros to the reduction instead of its (undefined) accumulators.
-  int tile = vb * 4 + wave;
-  const bool has_tile = tile < ge.ntile;
-  if (has_tile) {
-    one_tile(tile, std::true_type{});
-    for (tile += ge.stride; tile < ge.ntile; tile += ge.stride) one_tile(tile, std::false_type{});
-  }
+  for (int tile = vb * 4 + wave; tile < ge.ntile; tile += ge.stride) one_tile(tile);
   if (Znext) hc_seed_loads<ST, QUAD>(ge, Znext, m, zb);
   // ---- the item is complete: the four waves' accumulators meet in LDS, (w0 + w1) + (w2 + w3) ----
-  if (has_tile) {
-    if (QUAD) {   // the 4x4x1 tile's accumulators are partial over the pixel groups q: lanes l, l^16, l^32, l^48 -> (q0+q1)+(q2+q3)
+  if (QUAD) {   // the 4x4x1 tile's accumulators are partial over the pixel groups q: lanes l, l^16, l^32, l^48 -> (q0+q1)+(q2+q3)
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+    for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[ST - 1][ct][r];
-          v += __shfl_xor(v, 16);
-          v += __shfl_xor(v, 32);
-          acc[ST - 1][ct][r] = v;      // every lane now holds the total; lanes q = 0 are seeds 16(ST-1) .. +3, the rest is
-        }                              // written to rows >= m of the partial, which nobody reads
-    }
-#pragma unroll
-    for (int s = 0; s < ST; ++s)
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) red_wave[(s * 4 + ct) * 64 + lane] = acc[s][ct];
-  } else {
-#pragma unroll
-    for (int s = 0; s < ST; ++s)
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct) red_wave[(s * 4 + ct) * 64 + lane] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[ST - 1][ct][r];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        acc[ST - 1][ct][r] = v;      // every lane now holds the total; lanes q = 0 are seeds 16(ST-1) .. +3, the rest is
+      }                              // written to rows >= m of the partial, which nobody reads
   }
+#pragma unroll
+  for (int s = 0; s < ST; ++s)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) red_wave[(s * 4 + ct) * 64 + lane] = acc[s][ct];
+  hc_zero_acc<ST>(acc);   // on the matrix pipe, under the barrier
   __syncthreads();
   for (int s = wave; s < ST; s += 4) {
     f32x4 a[4][4], o[4];
@@ -933,6 +927,7 @@ __device__ __forceinline__ void hc_part(const HcGeom &ge, const float *__restric
   hc_seed_mask<ST, QUAD>(ge, m - 16 * s0, zb);
   hc_mask_tile(ge, held_t, xb);
   f32x4 acc[ST][4];
+  hc_zero_acc<ST>(acc);
   hc_item<ST, QUAD, QUAD>(ge, zb, kappa, b, vb, b, held_t, xa, xb, xc, held_b, held_t, acc, red,
                           dst_item + (size_t)16 * s0 * C, nullptr, 0);
 }
@@ -979,6 +974,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     hc_mask_tile(ge, held_t, xb);
     hc_seed_mask<ST, QUAD>(ge, m, zb);
     f32x4 acc[ST][4];
+    hc_zero_acc<ST>(acc);
     for (int j = 0; j < count; ++j) {
       const int item = first + j * step;
       const int nitem = j + 1 < count ? item + step : item;   // behind the last one: a harmless reload
