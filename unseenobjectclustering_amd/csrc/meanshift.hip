@@ -655,10 +655,6 @@ __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&x
         Sv[IS] = mfma4(f4c(xa[v], e), f4c(zb[IS][v], e), Sv[IS]);
       __builtin_amdgcn_sched_barrier(0);
     }
-    // The finished S tile is wanted in VGPRs (exp is VALU).  Saying so keeps hipcc from parking S chains in the AGPRs that
-    // hold loop-carried accumulators and moving those out of the way and back (24 v_accvgpr_mov per pixel tile in the
-    // flat-schedule kernel; every VALU instruction costs matrix-pipe time here).
-    asm volatile("" : "+v"(Sv[IS]));
     if (quad_s) {   // the four channel phases (lanes t, t+4, t+8, t+12 of a row): identical sum order on every lane
 #pragma unroll
       for (int r = 0; r < 4; ++r) Sv[IS][r] += dpp_f<0x128>(Sv[IS][r]);   // row_ror:8
