@@ -189,13 +189,26 @@ __global__ __launch_bounds__(1024) void crop_meanz_kernel(const int *__restrict_
   const int *lab = labels_crop + (size_t)k * SS;
   double sum = 0.0;
   int n = 0;
-  for (int i = threadIdx.x; i < SS; i += blockDim.x) {
-    const int l = lab[i];
-    const bool sel = any ? ((unsigned)l < (unsigned)NL && sk[l]) : true;
-    const float v = z[i];
-    if (sel && v > 0.f) {
-      sum += (double)v;
-      ++n;
+  // Seven elements of a thread's strided walk are loaded together and then added IN ORDER (the same additions as an
+  // element-at-a-time loop: bit-identical mean) — one block per ROI walks 49 elements per thread at 224x224, and with two
+  // dependent loads per element the loop was 49 serial memory round trips (44 us; 153 us beside other streams' kernels).
+  constexpr int UN = 7;
+  for (int i0 = threadIdx.x; i0 < SS; i0 += UN * blockDim.x) {
+    int l[UN];
+    float v[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int i = i0 + u * blockDim.x;
+      l[u] = i < SS ? lab[i] : -1;
+      v[u] = i < SS ? z[i] : 0.f;          // 0 is never selected (v > 0)
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const bool sel = any ? ((unsigned)l[u] < (unsigned)NL && sk[l[u]]) : true;
+      if (sel && v[u] > 0.f) {
+        sum += (double)v[u];
+        ++n;
+      }
     }
   }
 #pragma unroll
