@@ -1448,11 +1448,10 @@ static int run_select_seeds(const float *X, int batch, int n, int m, const int32
     sub = (batch - done + launches - 1) / launches;
     if (!fps_persistent_plan(sub, n, &bpi, &nslots)) break;  // (a smaller batch always fits if a larger one does)
     unsigned long long *gran = reinterpret_cast<unsigned long long *>(w.part[0]);
-    int *status = reinterpret_cast<int *>(w.part[1]);
     const size_t gbytes = (size_t)2 * sub * bpi * sizeof(unsigned long long);
-    if (gbytes > (size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax)) break;
-    UOC_HIP_CHECK(hipMemsetAsync(gran, 0, gbytes, st));  // tag 0 = "not published": re-initialised every call
-    UOC_HIP_CHECK(hipMemsetAsync(status, 0, sizeof(int), st));
+    if (gbytes + sizeof(unsigned long long) > (size_t)batch * FPS_MAX_BLOCKS * sizeof(ArgMax)) break;
+    int *status = reinterpret_cast<int *>(gran + (size_t)2 * sub * bpi);   // behind the granules: ONE fill for both
+    UOC_HIP_CHECK(hipMemsetAsync(gran, 0, gbytes + sizeof(unsigned long long), st));  // tag 0 = "not published": re-initialised every call
     // the LDS pixel slot is only touched when a lane owns more than FPP_RS pixels; without it the kernel needs no
     // dynamic LDS at all and can share a CU with another stream's convolution blocks (two frames in flight)
     const size_t lds = (nslots > FPP_RS) ? (size_t)FPP_LS * (C / 4) * FPP_THREADS * sizeof(float4) : 0;

@@ -427,7 +427,7 @@ static RoiWs carve_roi(void *base) {
   w.stats = (int *)take(NL * NSTAT * sizeof(int));
   w.lut = (int *)take(NL * sizeof(int));
   w.cnt = (int *)take((size_t)NL * NL * sizeof(int));
-  w.ov = (int *)take((size_t)NL * NL * sizeof(int));
+  w.ov = (int *)take((size_t)NL * NL * sizeof(int));     // directly behind cnt (the statistics' single fill relies on it)
   w.keep = (int *)take((size_t)NL * NL * sizeof(int));
   w.meanz = (float *)take(NL * sizeof(float));
   w.plan = (int *)take((size_t)(NL + NL * NL) * sizeof(int));
@@ -543,8 +543,8 @@ int uoc_roi_match_stats(const int32_t *d_labels_crop, const float *d_mask_crops,
   RoiWs w = carve_roi(d_ws);
   UOC_REQUIRE(ws_bytes >= w.total, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  UOC_HIP_CHECK(hipMemsetAsync(w.cnt, 0, (size_t)K * NL * sizeof(int), st));
-  UOC_HIP_CHECK(hipMemsetAsync(w.ov, 0, (size_t)K * NL * sizeof(int), st));
+  // cnt and ov are neighbours in the workspace (NL * NL ints each): one fill clears all of cnt and the K rows of ov in use
+  UOC_HIP_CHECK(hipMemsetAsync(w.cnt, 0, ((size_t)NL * NL + (size_t)K * NL) * sizeof(int), st));
   int gb = (S * S + 255) / 256;
   if (gb > 64) gb = 64;
   hipLaunchKernelGGL(crop_stats_kernel, dim3(gb, K), dim3(256), 0, st, d_labels_crop, d_mask_crops, S * S, w.cnt, w.ov);
@@ -574,8 +574,8 @@ int uoc_roi_match(const int32_t *d_labels_crop, const float *d_mask_crops, const
   hipStream_t st = (hipStream_t)stream;
   int *keep = d_keep ? d_keep : w.keep;
   int *plan = d_plan ? d_plan : w.plan;
-  UOC_HIP_CHECK(hipMemsetAsync(w.cnt, 0, (size_t)K * NL * sizeof(int), st));
-  UOC_HIP_CHECK(hipMemsetAsync(w.ov, 0, (size_t)K * NL * sizeof(int), st));
+  // cnt and ov are neighbours in the workspace (NL * NL ints each): one fill clears all of cnt and the K rows of ov in use
+  UOC_HIP_CHECK(hipMemsetAsync(w.cnt, 0, ((size_t)NL * NL + (size_t)K * NL) * sizeof(int), st));
   int gb = (S * S + 255) / 256;
   if (gb > 64) gb = 64;
   hipLaunchKernelGGL(crop_stats_kernel, dim3(gb, K), dim3(256), 0, st, d_labels_crop, d_mask_crops, S * S, w.cnt, w.ov);
