@@ -752,27 +752,30 @@ struct HcGeom {
 // whose xb row is zeroed, so out-of-range pixels contribute exactly 0; xb is zeroed only in the (rare) partial tile.
 // Rows are addressed from the launch's base X by a 32-bit GLOBAL pixel index (field b starts at row b * n; batch * n
 // rows of 256 bytes always fit: 2^31 rows would be 550 GB), so the field of a tile is a scalar offset, not a pointer.
-template <bool KQ>
-__device__ __forceinline__ void hc_load_tile(const HcGeom &ge, int b, int tl, float4 (&a)[4], float4 (&bb)[4],
-                                             float4 (&cc)[4]) {
+__device__ __forceinline__ void hc_load_tile(const HcGeom &ge, int b, int tl, float4 (&a)[4], float4 (&bb)[4]) {
   const int row0 = b * ge.n;
   const int base = row0 + min(tl, ge.ntile - 1) * 16, last = row0 + ge.n - 1;
   const float *__restrict__ X = ge.X;
   const int pa = min(base + ge.t, last);
 #pragma unroll
   for (int v = 0; v < 4; ++v) a[v] = *reinterpret_cast<const float4 *>(X + (size_t)(unsigned)pa * C + 16 * v + 4 * ge.q);
-  __builtin_amdgcn_sched_barrier(0);   // these four leave before the other views' address arithmetic (all twelve loads behind
+  __builtin_amdgcn_sched_barrier(0);   // these four leave before the other view's address arithmetic (all loads behind
                                        // all of it: 551 vs 546 us at 150 pixel tiles per wave)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int pb = min(base + 4 * ge.q + r, last);
     bb[r] = *reinterpret_cast<const float4 *>(X + (size_t)(unsigned)pb * C + 4 * ge.t);
   }
-  if (KQ) {   // third view of the tile for the 4x4x1 S step: pixel 4q + t%4, channels 16(t/4) + 4v .. +3
-    const int pc = min(base + 4 * ge.q + (ge.t & 3), last);
+}
+// Third view of a tile for the 4x4x1 S step: pixel 4q + t%4, channels 16(t/4) + 4v .. +3.  It feeds the LAST seed tile,
+// 60 % into the pixel tile, so it is loaded for the CURRENT tile at its top (its lines arrived with the other two views a
+// tile earlier) instead of being prefetched and handed over: 16 VALU moves and 16 registers less per pixel tile.
+__device__ __forceinline__ void hc_load_quad_view(const HcGeom &ge, int b, int tl, float4 (&cc)[4]) {
+  const int row0 = b * ge.n;
+  const int base = row0 + min(tl, ge.ntile - 1) * 16, last = row0 + ge.n - 1;
+  const int pc = min(base + 4 * ge.q + (ge.t & 3), last);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) cc[v] = *reinterpret_cast<const float4 *>(X + (size_t)(unsigned)pc * C + 16 * (ge.t >> 2) + 4 * v);
-  }
+  for (int v = 0; v < 4; ++v) cc[v] = *reinterpret_cast<const float4 *>(ge.X + (size_t)(unsigned)pc * C + 16 * (ge.t >> 2) + 4 * v);
 }
 // applied when the tile becomes the current one (a select on freshly loaded data would force a wait at the load)
 __device__ __forceinline__ void hc_mask_tile(const HcGeom &ge, int tl, float4 (&bb)[4]) {
@@ -846,8 +849,9 @@ __device__ __forceinline__ void hc_item(const HcGeom &ge, float4 (&zb)[ST][4], f
   auto one_tile = [&](int tile) {   // invariant: (held_b, held_t) == (b, tile)
     const bool more = tile + ge.stride < ge.ntile;
     const int nxt = more ? tile + ge.stride : nt;
-    float4 na[4], nbv[4], nc[4];
-    hc_load_tile<KQ>(ge, more ? b : nb, nxt, na, nbv, nc);
+    float4 na[4], nbv[4];
+    if (KQ) hc_load_quad_view(ge, b, tile, xc);
+    hc_load_tile(ge, more ? b : nb, nxt, na, nbv);
     __builtin_amdgcn_sched_barrier(0);
     hcr_tile<ST, QUAD>(xa, xb, xc, zb, acc, kappa);
 #pragma unroll
@@ -858,13 +862,6 @@ __device__ __forceinline__ void hc_item(const HcGeom &ge, float4 (&zb)[ST][4], f
       asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
                    : "=&v"(xb[v].x), "=&v"(xb[v].y), "=&v"(xb[v].z), "=&v"(xb[v].w)
                    : "v"(nbv[v].x), "v"(nbv[v].y), "v"(nbv[v].z), "v"(nbv[v].w));
-    }
-    if (KQ) {
-#pragma unroll
-      for (int v = 0; v < 4; ++v)
-        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                     : "=&v"(xc[v].x), "=&v"(xc[v].y), "=&v"(xc[v].z), "=&v"(xc[v].w)
-                     : "v"(nc[v].x), "v"(nc[v].y), "v"(nc[v].z), "v"(nc[v].w));
     }
     hc_mask_tile(ge, nxt, xb);
     held_b = more ? b : nb;
@@ -921,7 +918,7 @@ __device__ __forceinline__ void hc_part(const HcGeom &ge, const float *__restric
 #pragma unroll
   for (int v = 0; v < 4; ++v) xc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   int held_b = b, held_t = vb * 4 + ge.wave;
-  hc_load_tile<QUAD>(ge, b, held_t, xa, xb, xc);
+  hc_load_tile(ge, b, held_t, xa, xb);
   hc_seed_mask<ST, QUAD>(ge, m - 16 * s0, zb);
   hc_mask_tile(ge, held_t, xb);
   f32x4 acc[ST][4];
@@ -966,7 +963,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int v = 0; v < 4; ++v) xc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
     int held_b = b, held_t = vb * 4 + ge.wave;   // the tile whose pixels sit in xa / xb / xc
-    hc_load_tile<QUAD>(ge, b, held_t, xa, xb, xc);
+    hc_load_tile(ge, b, held_t, xa, xb);
     float4 zb[ST][4];
     hc_seed_loads<ST, QUAD>(ge, Z + (size_t)b * m * C, m, zb);
     hc_mask_tile(ge, held_t, xb);
@@ -981,7 +978,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (held_b != b || held_t != vb * 4 + ge.wave) {
         held_b = b;
         held_t = vb * 4 + ge.wave;
-        hc_load_tile<QUAD>(ge, b, held_t, xa, xb, xc);
+        hc_load_tile(ge, b, held_t, xa, xb);
         hc_mask_tile(ge, held_t, xb);
       }
       hc_item<ST, QUAD, QUAD>(ge, zb, kappa, b, vb, nb, nvb_ * 4 + ge.wave, xa, xb, xc, held_b, held_t, acc, red,
