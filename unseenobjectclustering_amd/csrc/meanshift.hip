@@ -842,32 +842,41 @@ __device__ __forceinline__ void hc_item(const HcGeom &ge, float4 (&zb)[ST][4], f
   const int lane = ge.lane, wave = ge.wave, t = ge.t, q = ge.q;
   f32x4 *red_wave = red + (size_t)wave * ST * 4 * 64;
   // The loads of the wave's NEXT tile (the first tile of the next item behind the last one of this item) are issued
-  // before the current tile's MFMAs and first read after them.  hipcc undoes a plain `xa = na` double buffer (it
-  // coalesces the copy, rotates the loop and ends up with load-then-wait at the top of every tile, ~0.8 us exposed per
-  // tile) and sinks the loads of a two-body ping-pong loop into the second body — so the hand-over is 32 opaque v_mov
-  // and a sched_barrier keeps the loads above the first MFMA.
-  auto one_tile = [&](int tile) {   // invariant: (held_b, held_t) == (b, tile)
-    const bool more = tile + ge.stride < ge.ntile;
+  // before the current tile's MFMAs and first read after them.  (hipcc undoes a plain `xa = na` double buffer: it
+  // coalesces the copy, rotates the loop and ends up with load-then-wait at the top of every tile, ~0.8 us exposed.)
+  // Ping-pong: a tile reads its pixels from one register set and prefetches the next tile into the other; the loop body
+  // holds two tiles with the roles swapped, so no registers are handed over per tile (32 VALU moves only when an item ends
+  // on the first half of the body).  The sched_barrier keeps each half's loads above its first MFMA.
+  float4 ya[4], yb[4];
+  auto one_tile = [&](int tile, float4(&ca)[4], float4(&cb)[4], float4(&na)[4], float4(&nbv)[4]) {
+    const bool more = tile + ge.stride < ge.ntile;   // invariant: (held_b, held_t) == (b, tile), pixels in ca / cb
     const int nxt = more ? tile + ge.stride : nt;
-    float4 na[4], nbv[4];
     if (KQ) hc_load_quad_view(ge, b, tile, xc);
     hc_load_tile(ge, more ? b : nb, nxt, na, nbv);
     __builtin_amdgcn_sched_barrier(0);
-    hcr_tile<ST, QUAD>(xa, xb, xc, zb, acc, kappa);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                   : "=&v"(xa[v].x), "=&v"(xa[v].y), "=&v"(xa[v].z), "=&v"(xa[v].w)
-                   : "v"(na[v].x), "v"(na[v].y), "v"(na[v].z), "v"(na[v].w));
-      asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
-                   : "=&v"(xb[v].x), "=&v"(xb[v].y), "=&v"(xb[v].z), "=&v"(xb[v].w)
-                   : "v"(nbv[v].x), "v"(nbv[v].y), "v"(nbv[v].z), "v"(nbv[v].w));
-    }
-    hc_mask_tile(ge, nxt, xb);
+    hcr_tile<ST, QUAD>(ca, cb, xc, zb, acc, kappa);
+    __builtin_amdgcn_sched_barrier(0);
+    hc_mask_tile(ge, nxt, nbv);
     held_b = more ? b : nb;
     held_t = nxt;
   };
-  for (int tile = vb * 4 + wave; tile < ge.ntile; tile += ge.stride) one_tile(tile);
+  for (int tile = vb * 4 + wave; tile < ge.ntile; tile += ge.stride) {
+    one_tile(tile, xa, xb, ya, yb);
+    tile += ge.stride;
+    if (tile >= ge.ntile) {        // the next item's first tile sits in the second set: hand it over
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                     : "=&v"(xa[v].x), "=&v"(xa[v].y), "=&v"(xa[v].z), "=&v"(xa[v].w)
+                     : "v"(ya[v].x), "v"(ya[v].y), "v"(ya[v].z), "v"(ya[v].w));
+        asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                     : "=&v"(xb[v].x), "=&v"(xb[v].y), "=&v"(xb[v].z), "=&v"(xb[v].w)
+                     : "v"(yb[v].x), "v"(yb[v].y), "v"(yb[v].z), "v"(yb[v].w));
+      }
+      break;
+    }
+    one_tile(tile, ya, yb, xa, xb);
+  }
   if (Znext) hc_seed_loads<ST, QUAD>(ge, Znext, m, zb);
   // ---- the item is complete: the four waves' accumulators meet in LDS, (w0 + w1) + (w2 + w3) ----
   if (QUAD) {   // the 4x4x1 tile's accumulators are partial over the pixel groups q: lanes l, l^16, l^32, l^48 -> (q0+q1)+(q2+q3)
