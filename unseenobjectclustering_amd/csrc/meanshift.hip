@@ -600,22 +600,34 @@ __global__ __launch_bounds__(HC_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 // e = (x*log2e_hi - t) + x*log2e_lo, re-enters as 2^e = 1 + e ln2.  Within ~1.5 ulp of exp(x); the library expf spends
 // four more instructions (rndne / sub / cvt / ldexp) on a range reduction v_exp does not need and five on guards that
 // cannot trigger for |x| <= 20.
+// The four elements of a lane (pixels 4q .. 4q+3 of the seed tile) go through the arithmetic steps as TWO PAIRS on
+// v_pk_mul_f32 / v_pk_fma_f32 (the same IEEE operation per element as the scalar instruction: bit-identical), v_exp per
+// element: 16 VALU instructions per seed tile instead of 28.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct ExpState {
-  float x, t, e, p;
+  f32x2 x, t, e, p;
 };
+constexpr int EXP_OPS = 16;   // per seed tile: ops 0-1 x = kappa s | 2-3 t | 4-5, 6-7 e | 8-11 v_exp | 12-13 e ln2 | 14-15 w
 #pragma clang fp contract(off)
-template <int STEP>
-__device__ __forceinline__ void exp_step(ExpState &e, float s, float kappa, float &w) {
-  if (STEP == 0) e.x = kappa * s;
-  if (STEP == 1) e.t = e.x * 0x1.715476p+0f;                        // log2(e) hi (0x3fb8aa3b)
-  if (STEP == 2) e.e = __builtin_fmaf(e.x, 0x1.715476p+0f, -e.t);
-  if (STEP == 3) e.e = __builtin_fmaf(e.x, 0x1.4ae0bep-26f, e.e);   // log2(e) lo (0x32a5705f)
-  if (STEP == 4) e.p = __builtin_amdgcn_exp2f(e.t);
-  if (STEP == 5) e.e = e.e * 0x1.62e43p-1f;                         // ln 2
-  if (STEP == 6) w = __builtin_fmaf(e.p, e.e, e.p);
+template <int OP>
+__device__ __forceinline__ void exp_op(ExpState (&es)[2], const f32x4 &s, float kappa, float (&w)[4]) {
+  constexpr int P = OP & 1;   // the pair (elements 2P, 2P + 1) of the packed ops
+  ExpState &e = es[P];
+  if (OP < 2) e.x = f32x2{kappa, kappa} * f32x2{s[2 * P], s[2 * P + 1]};
+  else if (OP < 4) e.t = e.x * f32x2{0x1.715476p+0f, 0x1.715476p+0f};                                   // log2(e) hi (0x3fb8aa3b)
+  else if (OP < 6) e.e = __builtin_elementwise_fma(e.x, f32x2{0x1.715476p+0f, 0x1.715476p+0f}, -e.t);
+  else if (OP < 8) e.e = __builtin_elementwise_fma(e.x, f32x2{0x1.4ae0bep-26f, 0x1.4ae0bep-26f}, e.e);   // log2(e) lo (0x32a5705f)
+  else if (OP < 12) {
+    constexpr int r = OP - 8;
+    es[r >> 1].p[r & 1] = __builtin_amdgcn_exp2f(es[r >> 1].t[r & 1]);
+  } else if (OP < 14) e.e = e.e * f32x2{0x1.62e43p-1f, 0x1.62e43p-1f};                                   // ln 2
+  else {
+    const f32x2 v = __builtin_elementwise_fma(e.p, e.e, e.p);
+    w[2 * P] = v.x;
+    w[2 * P + 1] = v.y;
+  }
 }
 #pragma clang fp contract(fast)
-constexpr int EXP_STEPS = 7;
 
 
 // One pixel tile (16 pixels) against all ST seed tiles.  3-stage pipeline over the seed tiles, fully unrolled; step i:
@@ -639,7 +651,7 @@ constexpr int EXP_STEPS = 7;
 template <int ST, bool QUAD, int I>
 __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&xb)[4], const float4 (&xc)[4],
                                          const float4 (&zb)[ST][4], f32x4 (&acc)[ST][4], f32x4 (&Sv)[ST + 2],
-                                         float (&wv)[ST + 2][4], ExpState (&es)[4], float kappa) {
+                                         float (&wv)[ST + 2][4], ExpState (&es)[2], float kappa) {
   // Sv / wv carry two spare rows so that the (never executed) I-1 / I-2 references of the first steps stay in range
   constexpr bool do_s = I < ST, do_a = I >= 2, do_e = I >= 1 && I - 1 < ST;
   constexpr int IS = I < ST ? I : 0, IE = I >= 1 ? I - 1 : 0, IA = I >= 2 ? I - 2 : 0;
@@ -663,7 +675,7 @@ __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&x
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  constexpr int nops = do_e ? 4 * EXP_STEPS : 0;
+  constexpr int nops = do_e ? EXP_OPS : 0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     if (do_a) {
@@ -673,22 +685,30 @@ __device__ __forceinline__ void hcr_step(const float4 (&xa)[4], const float4 (&x
       else
         acc[IA][ct] = mfma4(wv[IA][r], f4c(xb[r], ct), acc[IA][ct]);
     }
-    // the VALU steps that belong behind this slot, in 4 clusters per seed tile (behind MFMAs 3, 7, 11, 15): every
+    // the VALU ops that belong behind this slot, in 4 clusters per seed tile (behind MFMAs 3, 7, 11, 15): every
     // MFMA -> VALU switch costs ~2.7 cycles on top of the VALU's own 2 (scripts/mfma_shadow.hip)
     const int c = k >> 2, o0 = (k & 3) == 3 ? c * nops / 4 : 0, o1 = (k & 3) == 3 ? (c + 1) * nops / 4 : 0;
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {           // 28 / 4 = 7 steps per cluster; fixed trip count so it unrolls
+    for (int j = 0; j < 4; ++j) {           // 16 / 4 = 4 ops per cluster; fixed trip count so it unrolls
       const int o = o0 + j;
       if (o >= o1) continue;
-      const int step = o >> 2, r = o & 3;   // step-major, element-minor: consecutive ops are independent
-      switch (step) {
-        case 0: exp_step<0>(es[r], Sv[IE][r], kappa, wv[IE][r]); break;
-        case 1: exp_step<1>(es[r], 0.f, kappa, wv[IE][r]); break;
-        case 2: exp_step<2>(es[r], 0.f, kappa, wv[IE][r]); break;
-        case 3: exp_step<3>(es[r], 0.f, kappa, wv[IE][r]); break;
-        case 4: exp_step<4>(es[r], 0.f, kappa, wv[IE][r]); break;
-        case 5: exp_step<5>(es[r], 0.f, kappa, wv[IE][r]); break;
-        default: exp_step<6>(es[r], 0.f, kappa, wv[IE][r]); break;
+      switch (o) {                          // pair-minor within a step: consecutive ops are independent
+        case 0: exp_op<0>(es, Sv[IE], kappa, wv[IE]); break;
+        case 1: exp_op<1>(es, Sv[IE], kappa, wv[IE]); break;
+        case 2: exp_op<2>(es, Sv[IE], kappa, wv[IE]); break;
+        case 3: exp_op<3>(es, Sv[IE], kappa, wv[IE]); break;
+        case 4: exp_op<4>(es, Sv[IE], kappa, wv[IE]); break;
+        case 5: exp_op<5>(es, Sv[IE], kappa, wv[IE]); break;
+        case 6: exp_op<6>(es, Sv[IE], kappa, wv[IE]); break;
+        case 7: exp_op<7>(es, Sv[IE], kappa, wv[IE]); break;
+        case 8: exp_op<8>(es, Sv[IE], kappa, wv[IE]); break;
+        case 9: exp_op<9>(es, Sv[IE], kappa, wv[IE]); break;
+        case 10: exp_op<10>(es, Sv[IE], kappa, wv[IE]); break;
+        case 11: exp_op<11>(es, Sv[IE], kappa, wv[IE]); break;
+        case 12: exp_op<12>(es, Sv[IE], kappa, wv[IE]); break;
+        case 13: exp_op<13>(es, Sv[IE], kappa, wv[IE]); break;
+        case 14: exp_op<14>(es, Sv[IE], kappa, wv[IE]); break;
+        default: exp_op<15>(es, Sv[IE], kappa, wv[IE]); break;
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -701,7 +721,7 @@ __device__ __forceinline__ void hcr_tile_steps(const float4 (&xa)[4], const floa
                                                std::integer_sequence<int, Is...>) {
   f32x4 Sv[ST + 2];
   float wv[ST + 2][4];
-  ExpState es[4];
+  ExpState es[2];
   (hcr_step<ST, QUAD, Is>(xa, xb, xc, zb, acc, Sv, wv, es, kappa), ...);
 }
 
